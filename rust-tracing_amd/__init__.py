@@ -1,0 +1,368 @@
+"""ctypes bindings of the two shared libraries of this package.
+
+  librt_amd.so   csrc/  — the HIP renderer behind the C ABI of include/rt_amd.h (the product)
+  librt_host.so  host/  — the reference's host-side surface (scene builders, BVH build, camera, output stage)
+                          behind include/rt_host.h
+
+Python is plumbing here: tests and bench.py use it to hold device memory (torch), to launch one process per
+GPU (torch.distributed) and to call the C ABI.  Nothing in this module computes pixels, and there is no
+fallback: if librt_amd.so is missing or has no GPU to run on, calls raise.
+
+The package directory is named ``rust-tracing_amd`` (not importable with a plain ``import`` statement); load it
+with ``importlib.import_module("rust-tracing_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_DIR = _PKG_DIR / "lib"
+
+RT_ABI_VERSION = 1
+RT_TILE_W = 8
+RT_TILE_H = 8
+RT_OUT_FRAME = 0
+RT_OUT_TILES = 1
+
+# rt_hittable_kind
+RT_HITTABLE_NONE, RT_HITTABLE_SPHERE, RT_HITTABLE_QUAD, RT_HITTABLE_LIST, RT_HITTABLE_TRANSLATE, \
+    RT_HITTABLE_ROTATE_Y, RT_HITTABLE_BVH, RT_HITTABLE_CONSTANT_MEDIUM = range(8)
+# rt_material_kind
+RT_MATERIAL_LAMBERTIAN, RT_MATERIAL_METAL, RT_MATERIAL_DIELECTRIC, RT_MATERIAL_DIFFUSE_LIGHT, \
+    RT_MATERIAL_ISOTROPIC = range(1, 6)
+# rt_texture_kind
+RT_TEXTURE_SOLID, RT_TEXTURE_CHECKER, RT_TEXTURE_IMAGE, RT_TEXTURE_NOISE = range(1, 5)
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+    def tuple(self):
+        return (self.x, self.y, self.z)
+
+
+class Aabb(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+
+
+class Ref(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("center", Vec3), ("radius", C.c_double), ("center_vec", Vec3), ("is_moving", C.c_int32),
+                ("material", C.c_int32)]
+
+
+class Quad(C.Structure):
+    _fields_ = [("q", Vec3), ("u", Vec3), ("v", Vec3), ("w", Vec3), ("normal", Vec3), ("d", C.c_double),
+                ("material", C.c_int32), ("_pad", C.c_int32)]
+
+
+class List(C.Structure):
+    _fields_ = [("first", C.c_int32), ("count", C.c_int32)]
+
+
+class Translate(C.Structure):
+    _fields_ = [("object", Ref), ("offset", Vec3)]
+
+
+class RotateY(C.Structure):
+    _fields_ = [("object", Ref), ("sin_theta", C.c_double), ("cos_theta", C.c_double)]
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bbox", Aabb), ("is_leaf", C.c_int32), ("left", C.c_int32), ("right", C.c_int32),
+                ("object", Ref), ("_pad", C.c_int32)]
+
+
+class Bvh(C.Structure):
+    _fields_ = [("root", C.c_int32), ("_pad", C.c_int32)]
+
+
+class ConstantMedium(C.Structure):
+    _fields_ = [("boundary", Ref), ("neg_inv_density", C.c_double), ("phase_material", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("texture", C.c_int32), ("albedo", Vec3), ("fuzz", C.c_double),
+                ("ir", C.c_double)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("even", C.c_int32), ("odd", C.c_int32), ("image", C.c_int32),
+                ("perlin", C.c_int32), ("_pad", C.c_int32), ("color", Vec3), ("inv_scale", C.c_double),
+                ("scale", C.c_double)]
+
+
+class Perlin(C.Structure):
+    _fields_ = [("ranvec", Vec3 * 256), ("perm_x", C.c_int32 * 256), ("perm_y", C.c_int32 * 256),
+                ("perm_z", C.c_int32 * 256)]
+
+
+class Image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", C.POINTER(C.c_uint8))]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("_pad", C.c_uint32), ("world", Ref),
+                ("n_spheres", C.c_int32), ("n_quads", C.c_int32), ("n_lists", C.c_int32),
+                ("n_list_items", C.c_int32), ("n_translates", C.c_int32), ("n_rotates", C.c_int32),
+                ("n_bvh_nodes", C.c_int32), ("n_bvhs", C.c_int32), ("n_media", C.c_int32),
+                ("n_materials", C.c_int32), ("n_textures", C.c_int32), ("n_perlins", C.c_int32),
+                ("n_images", C.c_int32), ("_pad2", C.c_int32),
+                ("spheres", C.POINTER(Sphere)), ("quads", C.POINTER(Quad)), ("lists", C.POINTER(List)),
+                ("list_items", C.POINTER(Ref)), ("translates", C.POINTER(Translate)),
+                ("rotates", C.POINTER(RotateY)), ("bvh_nodes", C.POINTER(BvhNode)), ("bvhs", C.POINTER(Bvh)),
+                ("media", C.POINTER(ConstantMedium)), ("materials", C.POINTER(Material)),
+                ("textures", C.POINTER(Texture)), ("perlins", C.POINTER(Perlin)), ("images", C.POINTER(Image))]
+
+
+class Camera(C.Structure):
+    _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("samples_per_pixel", C.c_int32),
+                ("max_depth", C.c_int32), ("background", Vec3), ("center", Vec3), ("pixel00_loc", Vec3),
+                ("pixel_delta_u", Vec3), ("pixel_delta_v", Vec3), ("defocus_angle", C.c_double),
+                ("defocus_disk_u", Vec3), ("defocus_disk_v", Vec3)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
+                ("max_depth", C.c_int32), ("accumulate", C.c_int32), ("shard_index", C.c_int32),
+                ("shard_count", C.c_int32), ("out_layout", C.c_int32), ("device", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "sphere_tests", "quad_tests",
+                                          "medium_visits", "rng_draws", "noise_evals", "image_lookups",
+                                          "instance_enters")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("node_bytes", "sphere_bytes", "quad_bytes", "instance_bytes",
+                                          "medium_bytes", "material_bytes", "texture_bytes", "perlin_bytes",
+                                          "image_bytes")] + \
+               [(n, C.c_uint32) for n in ("n_nodes", "n_spheres", "n_quads", "n_instances", "n_media",
+                                          "max_instance_depth", "lds_nodes", "lds_bytes")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneOptions(C.Structure):
+    _fields_ = [("scene", C.c_int32), ("bvh_policy", C.c_int32), ("scene_seed", C.c_uint64),
+                ("image_width", C.c_int64), ("aspect_ratio", C.c_double), ("samples_per_pixel", C.c_int32),
+                ("max_depth", C.c_int32), ("earth_image", C.c_char_p)]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+# every symbol include/rt_amd.h declares: name -> (restype, argtypes)
+RT_AMD_SYMBOLS = {
+    "rt_device_count": (C.c_int, []),
+    "rt_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_scene_destroy": (None, [C.c_void_p]),
+    "rt_scene_get_stats": (C.c_int, [C.c_void_p, C.POINTER(SceneStats)]),
+    "rt_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.POINTER(C.c_double)]),
+    "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
+    "rt_render_device_counted": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
+                                           C.c_void_p, C.POINTER(Counters)]),
+    "rt_out_size": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_tiles_to_frame_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_resolve_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_last_error": (C.c_char_p, []),
+    "rt_version": (C.c_char_p, []),
+}
+
+# every symbol include/rt_host.h declares
+RT_HOST_SYMBOLS = {
+    "rth_scene_build": (C.c_int, [C.POINTER(SceneOptions), C.POINTER(C.c_void_p)]),
+    "rth_scene_destroy": (None, [C.c_void_p]),
+    "rth_scene_desc": (C.POINTER(SceneDesc), [C.c_void_p]),
+    "rth_scene_camera": (C.POINTER(Camera), [C.c_void_p]),
+    "rth_resolve_rgb8": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
+    "rth_write_png": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "rth_synthetic_earth": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
+    "rth_load_image": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                 C.c_int64]),
+    "rth_last_error": (C.c_char_p, []),
+}
+
+
+def _bind(lib, table):
+    for name, (restype, argtypes) in table.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+_host_lib = None
+_amd_lib = None
+
+
+def host_lib():
+    """librt_host.so (CPU only)."""
+    global _host_lib
+    if _host_lib is None:
+        path = LIB_DIR / "librt_host.so"
+        if not path.exists():
+            raise RtError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _host_lib = _bind(C.CDLL(str(path)), RT_HOST_SYMBOLS)
+    return _host_lib
+
+
+def amd_lib():
+    """librt_amd.so (HIP).  Loading works without a GPU; rendering does not."""
+    global _amd_lib
+    if _amd_lib is None:
+        path = LIB_DIR / "librt_amd.so"
+        if not path.exists():
+            raise RtError(f"{path} is missing: the HIP renderer is not built and there is no fallback; "
+                          "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _amd_lib = _bind(C.CDLL(str(path), mode=C.RTLD_GLOBAL), RT_AMD_SYMBOLS)
+    return _amd_lib
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise RtError(f"{where} failed ({rc}): {amd_lib().rt_last_error().decode(errors='replace')}")
+
+
+class HostScene:
+    """A scene built by the host library: the reference's `main` up to the call of render()
+    (scene function -> BVHNode::new -> Camera), described as rt_scene_desc + rt_camera."""
+
+    def __init__(self, scene: int, *, scene_seed: int = 1, width: int = 0, aspect: float = 0.0, spp: int = 0,
+                 depth: int = 0, earth_image: str | None = None, bvh: str = "reference"):
+        lib = host_lib()
+        self._earth = earth_image.encode() if earth_image else None
+        opts = SceneOptions(scene=scene, bvh_policy=1 if bvh == "sah" else 0, scene_seed=scene_seed,
+                            image_width=width, aspect_ratio=aspect, samples_per_pixel=spp, max_depth=depth,
+                            earth_image=self._earth)
+        handle = C.c_void_p()
+        if lib.rth_scene_build(C.byref(opts), C.byref(handle)) != 0:
+            raise RtError(lib.rth_last_error().decode(errors="replace"))
+        self._handle = handle
+        self.desc = lib.rth_scene_desc(handle).contents
+        self.camera = lib.rth_scene_camera(handle).contents
+
+    @property
+    def width(self):
+        return self.camera.image_width
+
+    @property
+    def height(self):
+        return self.camera.image_height
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            host_lib().rth_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_params(*, seed=1, sample_begin=0, sample_end=0, max_depth=0, accumulate=False, shard_index=0,
+                  shard_count=1, out_layout=RT_OUT_FRAME, device=0) -> RenderParams:
+    return RenderParams(seed=seed, sample_begin=sample_begin, sample_end=sample_end, max_depth=max_depth,
+                        accumulate=1 if accumulate else 0, shard_index=shard_index, shard_count=shard_count,
+                        out_layout=out_layout, device=device)
+
+
+def out_size(width, height, out_layout=RT_OUT_FRAME, shard_index=0, shard_count=1) -> int:
+    return int(amd_lib().rt_out_size(width, height, out_layout, shard_index, shard_count))
+
+
+class DeviceScene:
+    """rt_scene handle: the compiled scene resident in one GPU's HBM."""
+
+    def __init__(self, host_scene: HostScene, device: int = 0):
+        lib = amd_lib()
+        self.host_scene = host_scene  # keeps desc memory alive during create
+        self.device = device
+        handle = C.c_void_p()
+        _check(lib.rt_scene_create(C.byref(host_scene.desc), device, C.byref(handle)), "rt_scene_create")
+        self._handle = handle
+
+    def stats(self) -> dict:
+        st = SceneStats()
+        _check(amd_lib().rt_scene_get_stats(self._handle, C.byref(st)), "rt_scene_get_stats")
+        return st.as_dict()
+
+    def render(self, params: RenderParams, camera: Camera | None = None):
+        """rt_render: host buffer out (numpy float64)."""
+        import numpy as np
+        cam = camera if camera is not None else self.host_scene.camera
+        n = out_size(cam.image_width, cam.image_height, params.out_layout, params.shard_index, params.shard_count)
+        out = np.zeros(n, dtype=np.float64)
+        _check(amd_lib().rt_render(self._handle, C.byref(cam), C.byref(params),
+                                   out.ctypes.data_as(C.POINTER(C.c_double))), "rt_render")
+        return out
+
+    def render_device(self, params: RenderParams, d_out_ptr: int, stream: int = 0, camera: Camera | None = None):
+        """rt_render_device: `d_out_ptr` is a device pointer (e.g. torch tensor .data_ptr()), `stream` a hipStream_t."""
+        cam = camera if camera is not None else self.host_scene.camera
+        _check(amd_lib().rt_render_device(self._handle, C.byref(cam), C.byref(params), C.c_void_p(d_out_ptr),
+                                          C.c_void_p(stream)), "rt_render_device")
+
+    def render_device_counted(self, params: RenderParams, d_out_ptr: int, stream: int = 0,
+                              camera: Camera | None = None) -> dict:
+        cam = camera if camera is not None else self.host_scene.camera
+        cnt = Counters()
+        _check(amd_lib().rt_render_device_counted(self._handle, C.byref(cam), C.byref(params),
+                                                  C.c_void_p(d_out_ptr), C.c_void_p(stream), C.byref(cnt)),
+               "rt_render_device_counted")
+        return cnt.as_dict()
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            amd_lib().rt_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tiles_to_frame_device(width, height, shard_count, d_gathered_ptr: int, d_frame_ptr: int, stream: int = 0):
+    _check(amd_lib().rt_tiles_to_frame_device(width, height, shard_count, C.c_void_p(d_gathered_ptr),
+                                              C.c_void_p(d_frame_ptr), C.c_void_p(stream)),
+           "rt_tiles_to_frame_device")
+
+
+def resolve_rgb8_device(width, height, spp, d_frame_ptr: int, d_rgb8_ptr: int, stream: int = 0):
+    _check(amd_lib().rt_resolve_rgb8_device(width, height, spp, C.c_void_p(d_frame_ptr), C.c_void_p(d_rgb8_ptr),
+                                            C.c_void_p(stream)), "rt_resolve_rgb8_device")
+
+
+def resolve_rgb8_host(width, height, spp, sums):
+    """color_to_rgb(sum / spp) on the host (librt_host; src/renderer.rs:55-58)."""
+    import numpy as np
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    out = np.zeros(width * height * 3, dtype=np.uint8)
+    if host_lib().rth_resolve_rgb8(width, height, spp, sums.ctypes.data_as(C.POINTER(C.c_double)),
+                                   out.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+        raise RtError(host_lib().rth_last_error().decode(errors="replace"))
+    return out.reshape(height, width, 3)
+
+
+def write_png(path, rgb8):
+    import numpy as np
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    if host_lib().rth_write_png(os.fsencode(path), w, h, rgb8.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+        raise RtError(host_lib().rth_last_error().decode(errors="replace"))

@@ -1,0 +1,214 @@
+#include "image_io.hpp"
+#include "jpeg_decoder.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <zlib.h>
+
+namespace rt {
+
+// ---- procedural stand-in for the earth map: integer arithmetic only, so every machine produces the same bytes
+static inline uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// lattice value in [0, 65535]; x wraps with period `px` so that the u = 0 / u = 1 seam is continuous
+static inline uint32_t lattice(int32_t ix, int32_t iy, int32_t px, uint32_t oct) {
+    ix %= px; if (ix < 0) ix += px;
+    return hash_u32((uint32_t)ix * 0x9E3779B1u ^ hash_u32((uint32_t)iy + 0x85EBCA6Bu * (oct + 1u))) & 0xFFFFu;
+}
+// bilinear value noise at fixed-point position (x, y) in 16.16 lattice units
+static inline uint32_t value_noise(uint32_t x, uint32_t y, int32_t px, uint32_t oct) {
+    int32_t ix = (int32_t)(x >> 16), iy = (int32_t)(y >> 16);
+    uint64_t fx = x & 0xFFFFu, fy = y & 0xFFFFu;
+    // smoothstep weights in 0..65536
+    fx = (fx * fx >> 16) * (3u * 65536u - 2u * fx) >> 16;
+    fy = (fy * fy >> 16) * (3u * 65536u - 2u * fy) >> 16;
+    uint64_t a = lattice(ix, iy, px, oct), b = lattice(ix + 1, iy, px, oct);
+    uint64_t c = lattice(ix, iy + 1, px, oct), d = lattice(ix + 1, iy + 1, px, oct);
+    uint64_t top = a * (65536u - fx) + b * fx, bot = c * (65536u - fx) + d * fx; // <= 2^32
+    return (uint32_t)(((top >> 16) * (65536u - fy) + (bot >> 16) * fy) >> 16);   // 0..65535
+}
+
+ImageRGB8 synthetic_earth(int32_t width, int32_t height) {
+    if (width <= 0 || height <= 0) throw std::runtime_error("synthetic_earth: bad size");
+    auto px = std::make_shared<std::vector<uint8_t>>((size_t)width * (size_t)height * 3u);
+    const int32_t base_period = 8; // lattice cells around the globe at octave 0
+    for (int32_t j = 0; j < height; ++j) {
+        for (int32_t i = 0; i < width; ++i) {
+            uint32_t e = 0, amp = 32768u;
+            for (uint32_t o = 0; o < 6; ++o) {
+                int32_t period = base_period << o;
+                uint32_t x = (uint32_t)(((uint64_t)i * (uint64_t)period << 16) / (uint64_t)width);
+                uint32_t y = (uint32_t)(((uint64_t)j * (uint64_t)(period / 2) << 16) / (uint64_t)height);
+                e += (uint32_t)(((uint64_t)value_noise(x, y, period, o) * amp) >> 16);
+                amp >>= 1;
+            }
+            // e in [0, 65535); latitude in 0..32768 from the equator to the poles
+            int32_t lat = (int32_t)(((int64_t)std::abs(2 * j - height + 1) << 15) / height);
+            uint32_t dither = hash_u32((uint32_t)(j * width + i)) & 7u;
+            uint8_t r, g, b;
+            if (lat * 2 + (int32_t)(e >> 3) > 66000) { // ice caps
+                r = (uint8_t)(232 + dither); g = (uint8_t)(238 + dither); b = (uint8_t)(244 + dither);
+            } else if (e < 33000u) { // ocean: deeper = darker
+                uint32_t d = e >> 9; // 0..64
+                r = (uint8_t)(6 + (d >> 2) + dither);
+                g = (uint8_t)(22 + d + dither);
+                b = (uint8_t)(70 + 2 * d + dither);
+            } else { // land: green lowlands to brown highlands
+                uint32_t hgt = (e - 33000u) >> 8; // 0..127
+                if (hgt > 127) hgt = 127;
+                r = (uint8_t)(40 + hgt + dither);
+                g = (uint8_t)(110 - (hgt >> 1) + dither);
+                b = (uint8_t)(30 + (hgt >> 2) + dither);
+            }
+            uint8_t *p = px->data() + ((size_t)j * (size_t)width + (size_t)i) * 3u;
+            p[0] = r; p[1] = g; p[2] = b;
+        }
+    }
+    ImageRGB8 img;
+    img.width = width;
+    img.height = height;
+    img.pixels = px;
+    return img;
+}
+
+static ImageRGB8 load_ppm(const std::string &path, FILE *f) {
+    int w = 0, h = 0, maxv = 0;
+    char magic[3] = {0, 0, 0};
+    auto skip = [&]() {
+        int c;
+        for (;;) {
+            c = fgetc(f);
+            if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); }
+            else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+            else { ungetc(c, f); break; }
+        }
+    };
+    if (fread(magic, 1, 2, f) != 2 || magic[0] != 'P' || magic[1] != '6')
+        throw std::runtime_error("load_image_rgb8: " + path + ": not a binary PPM");
+    skip(); if (fscanf(f, "%d", &w) != 1) throw std::runtime_error("load_image_rgb8: bad PPM header");
+    skip(); if (fscanf(f, "%d", &h) != 1) throw std::runtime_error("load_image_rgb8: bad PPM header");
+    skip(); if (fscanf(f, "%d", &maxv) != 1) throw std::runtime_error("load_image_rgb8: bad PPM header");
+    fgetc(f); // single whitespace after maxval
+    if (w <= 0 || h <= 0 || maxv != 255) throw std::runtime_error("load_image_rgb8: unsupported PPM");
+    auto px = std::make_shared<std::vector<uint8_t>>((size_t)w * (size_t)h * 3u);
+    if (fread(px->data(), 1, px->size(), f) != px->size())
+        throw std::runtime_error("load_image_rgb8: " + path + ": truncated PPM");
+    ImageRGB8 img;
+    img.width = w; img.height = h; img.pixels = px;
+    return img;
+}
+
+ImageRGB8 load_image_rgb8(const std::string &path) {
+    if (path.rfind("synthetic:", 0) == 0) {
+        int w = 0, h = 0;
+        if (sscanf(path.c_str() + 10, "%dx%d", &w, &h) != 2)
+            throw std::runtime_error("load_image_rgb8: expected synthetic:WxH, got " + path);
+        return synthetic_earth(w, h);
+    }
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("load_image_rgb8: cannot open " + path);
+    unsigned char head[2] = {0, 0};
+    size_t n = fread(head, 1, 2, f);
+    rewind(f);
+    try {
+        ImageRGB8 img;
+        if (n == 2 && head[0] == 'P' && head[1] == '6') {
+            img = load_ppm(path, f);
+        } else if (n == 2 && head[0] == 0xFF && head[1] == 0xD8) {
+            std::vector<uint8_t> bytes;
+            fseek(f, 0, SEEK_END);
+            long sz = ftell(f);
+            rewind(f);
+            bytes.resize((size_t)sz);
+            if (fread(bytes.data(), 1, bytes.size(), f) != bytes.size())
+                throw std::runtime_error("load_image_rgb8: short read on " + path);
+            img = decode_baseline_jpeg(bytes.data(), bytes.size());
+        } else {
+            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6 or baseline JPEG)");
+        }
+        fclose(f);
+        return img;
+    } catch (...) {
+        fclose(f);
+        throw;
+    }
+}
+
+// ---- PNG ------------------------------------------------------------------------------------------------
+static void put_u32(std::vector<uint8_t> &v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+static void put_chunk(std::vector<uint8_t> &out, const char type[4], const uint8_t *data, size_t len) {
+    put_u32(out, (uint32_t)len);
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    if (len) out.insert(out.end(), data, data + len);
+    uint32_t crc = (uint32_t)crc32(0L, out.data() + start, (uInt)(len + 4));
+    put_u32(out, crc);
+}
+static inline int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+bool write_png_rgb8(const std::string &path, int32_t width, int32_t height, const uint8_t *rgb) {
+    if (width <= 0 || height <= 0 || !rgb) return false;
+    const size_t stride = (size_t)width * 3u;
+    std::vector<uint8_t> raw((stride + 1u) * (size_t)height);
+    std::vector<uint8_t> cand(stride), zero(stride, 0);
+    for (int32_t y = 0; y < height; ++y) {
+        const uint8_t *cur = rgb + (size_t)y * stride;
+        const uint8_t *up = y ? rgb + (size_t)(y - 1) * stride : zero.data();
+        // adaptive filter: minimum sum of absolute (signed) residuals
+        int best_f = 0; uint64_t best_cost = ~0ull;
+        for (int f = 0; f < 5; ++f) {
+            uint64_t cost = 0;
+            for (size_t x = 0; x < stride; ++x) {
+                int a = x >= 3 ? cur[x - 3] : 0, b = up[x], c = x >= 3 ? up[x - 3] : 0, v = cur[x], r;
+                switch (f) {
+                case 0: r = v; break;
+                case 1: r = v - a; break;
+                case 2: r = v - b; break;
+                case 3: r = v - ((a + b) >> 1); break;
+                default: r = v - paeth(a, b, c); break;
+                }
+                cost += (uint64_t)std::abs((int)(int8_t)(uint8_t)r);
+            }
+            if (cost < best_cost) { best_cost = cost; best_f = f; }
+        }
+        uint8_t *dst = raw.data() + (size_t)y * (stride + 1u);
+        dst[0] = (uint8_t)best_f;
+        for (size_t x = 0; x < stride; ++x) {
+            int a = x >= 3 ? cur[x - 3] : 0, b = up[x], c = x >= 3 ? up[x - 3] : 0, v = cur[x], r;
+            switch (best_f) {
+            case 0: r = v; break;
+            case 1: r = v - a; break;
+            case 2: r = v - b; break;
+            case 3: r = v - ((a + b) >> 1); break;
+            default: r = v - paeth(a, b, c); break;
+            }
+            dst[1 + x] = (uint8_t)r;
+        }
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), Z_DEFAULT_COMPRESSION) != Z_OK) return false;
+
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_u32(ihdr, (uint32_t)width); put_u32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    put_chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    put_chunk(out, "IDAT", z.data(), (size_t)zlen);
+    put_chunk(out, "IEND", nullptr, 0);
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok;
+}
+
+} // namespace rt

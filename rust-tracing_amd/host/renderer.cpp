@@ -1,0 +1,81 @@
+#include "renderer.hpp"
+#include "color.hpp"
+#include "image_io.hpp"
+#include "rt_amd.h"
+#include <chrono>
+#include <cstdio>
+#include <stdexcept>
+#include <thread>
+
+namespace rt {
+
+std::vector<double> render_sums(const Camera &camera, const Hittable &world, const RenderOptions &opt) {
+    SceneDescriber sd;
+    const rt_ref root = world.describe(sd);
+    const rt_scene_desc desc = sd.desc(root);
+    const rt_camera cam = camera.pod();
+
+    const int ngpu = opt.gpus < 1 ? 1 : opt.gpus;
+    if (rt_device_count() < ngpu)
+        throw std::runtime_error("render: " + std::to_string(ngpu) + " GPU(s) requested, " +
+                                 std::to_string(rt_device_count()) + " visible");
+
+    std::vector<double> sums((size_t)cam.image_width * (size_t)cam.image_height * 3u, 0.0);
+    std::vector<std::string> errors((size_t)ngpu);
+    std::vector<std::thread> workers;
+    // one host thread per device; each renders the tiles k with k % ngpu == g into its own pixels of `sums`
+    for (int g = 0; g < ngpu; ++g) {
+        workers.emplace_back([&, g]() {
+            rt_scene *scene = nullptr;
+            if (rt_scene_create(&desc, g, &scene) != RT_OK) { errors[g] = rt_last_error(); return; }
+            rt_render_params p{};
+            p.seed = opt.seed;
+            p.sample_begin = 0;
+            p.sample_end = cam.samples_per_pixel;
+            p.max_depth = cam.max_depth;
+            p.shard_index = g;
+            p.shard_count = ngpu;
+            p.out_layout = RT_OUT_FRAME;
+            p.device = g;
+            if (rt_render(scene, &cam, &p, sums.data()) != RT_OK) errors[g] = rt_last_error();
+            rt_scene_destroy(scene);
+        });
+    }
+    for (auto &w : workers) w.join();
+    for (const auto &e : errors)
+        if (!e.empty()) throw std::runtime_error("render: " + e);
+    return sums;
+}
+
+std::vector<uint8_t> resolve_rgb8(const std::vector<double> &sums, int32_t spp) {
+    std::vector<uint8_t> px(sums.size());
+    const FP inv = 1.0 / (FP)spp; // `c / spp as FP` is a multiply by the reciprocal (src/vec3.rs:244-249)
+    for (size_t i = 0; i + 2 < sums.size(); i += 3) {
+        const auto rgb = color_to_rgb(Color(sums[i] * inv, sums[i + 1] * inv, sums[i + 2] * inv));
+        px[i] = rgb[0]; px[i + 1] = rgb[1]; px[i + 2] = rgb[2];
+    }
+    return px;
+}
+
+void render(std::shared_ptr<Camera> camera, std::shared_ptr<Hittable> world, const std::string &output_file_name,
+            const RenderOptions &opt) {
+    using clock = std::chrono::steady_clock;
+    auto now = clock::now();
+    const std::vector<double> sums = render_sums(*camera, *world, opt);
+    const double render_s = std::chrono::duration<double>(clock::now() - now).count();
+    if (!opt.quiet) {
+        const double msamples = (double)camera->image_width * (double)camera->image_height *
+                                (double)camera->samples_per_pixel / 1e6;
+        printf("Render time: %.2fs (%.1f Msamples/s)\n", render_s, msamples / render_s);
+    }
+
+    now = clock::now();
+    const std::vector<uint8_t> px = resolve_rgb8(sums, camera->samples_per_pixel);
+    if (!write_png_rgb8(output_file_name + ".png", (int32_t)camera->image_width, (int32_t)camera->image_height,
+                        px.data()))
+        throw std::runtime_error("Should've encoded the image into a file."); // src/renderer.rs:72
+    if (!opt.quiet)
+        printf("PNG encoding: %.2fs\n", std::chrono::duration<double>(clock::now() - now).count());
+}
+
+} // namespace rt

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/reference_screenshot_stats.json from the reference's published screenshots.
+
+The reference (Husenap/rust-tracing) has no tests or golden vectors; the only outputs it publishes are the
+PNGs under screenshots/ (README.md:20-37).  Two of them show scenes with no build-time randomness, rendered by the committed code at the committed
+camera settings, so a converged render of the same scene must reproduce them up to Monte-Carlo noise:
+    cornell_box.png    600x600    src/main.rs:344-421
+    cornell_smoke.png  600x600    src/main.rs:423-506
+(checker.png shows the deterministic two_spheres scene too, but it was rendered by an older revision with a
+gradient sky: its sky pixels are (229,240,255), whereas the committed constant background (0.7,0.8,1.0),
+src/main.rs:163, encodes to (217,231,255).  Geometry agrees, colours cannot, so it is not used as a pin.)
+This script reduces each to a GRID x GRID table of block means — both of the sRGB bytes and of the
+linearised values (((byte + 0.5)/256)^2.2: the centre of the interval of linear values that
+color_to_rgb, src/color.rs:12-19, maps to that byte — `(256 * x^(1/2.2)) as u8` truncates) — which is the
+fixture the tests compare against.  It is DATA derived from the reference's images, not reference source.
+
+Run in the build container (needs /root/reference); the GPU box only sees the committed JSON.
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+from PIL import Image
+
+REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
+OUT = Path(__file__).resolve().parent / "reference_screenshot_stats.json"
+GRID = 12
+
+SHOTS = {
+    "cornell_box": {"file": "screenshots/cornell_box.png", "scene": 6, "source": "src/main.rs:344-421"},
+    "cornell_smoke": {"file": "screenshots/cornell_smoke.png", "scene": 7, "source": "src/main.rs:423-506"},
+}
+
+
+def block_means(a, grid):
+    h, w, c = a.shape
+    ys = [round(k * h / grid) for k in range(grid + 1)]
+    xs = [round(k * w / grid) for k in range(grid + 1)]
+    out = np.zeros((grid, grid, c))
+    for r in range(grid):
+        for q in range(grid):
+            out[r, q] = a[ys[r]:ys[r + 1], xs[q]:xs[q + 1]].reshape(-1, c).mean(axis=0)
+    return out
+
+
+def main():
+    result = {"grid": GRID, "note": "block means of the reference's screenshots; rows top to bottom", "shots": {}}
+    for name, info in SHOTS.items():
+        img = np.asarray(Image.open(REF / info["file"]).convert("RGB"), dtype=np.float64)
+        lin = ((img + 0.5) / 256.0) ** 2.2
+        result["shots"][name] = {
+            "file": info["file"], "scene": info["scene"], "source": info["source"],
+            "width": int(img.shape[1]), "height": int(img.shape[0]),
+            "mean_srgb": [round(float(x), 4) for x in img.reshape(-1, 3).mean(axis=0)],
+            "mean_linear": [round(float(x), 6) for x in lin.reshape(-1, 3).mean(axis=0)],
+            "blocks_srgb": np.round(block_means(img, GRID), 3).tolist(),
+            "blocks_linear": np.round(block_means(lin, GRID), 6).tolist(),
+        }
+    OUT.write_text(json.dumps(result, indent=1) + "\n")
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
