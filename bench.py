@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the render hot path on N MI355X (BASELINE.json's metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one full frame of the workload: every pixel x every sample traced by the HIP kernel
+(rust-tracing_amd/csrc/rt_kernel.hip) through the C ABI, the scene resident in HBM before the clock starts.
+With N > 1 the frame's 8x8 tiles are dealt round-robin to the ranks (no data-path collective) and ONE gather
+(RCCL) brings the tile buffers to rank 0, which reassembles the frame on its GPU — all inside the timed step.
+The image is the same for every N (tests/test_gpu_parity.py, tests/test_sharding_gloo.py), so total work is
+fixed: strong scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# BASELINE.json configs; [1] is the one the metric is quoted on
+WORKLOADS = {
+    "c1": dict(name="random-spheres 400x225, 10 spp, depth 10", scene=0, width=400, aspect=16.0 / 9.0, spp=10, depth=10),
+    "c2": dict(name="random-spheres 1200x800, 500 spp, depth 50", scene=0, width=1200, aspect=1.5, spp=500, depth=50),
+    "c3": dict(name="cornell box 600x600, 1000 spp, depth 50", scene=6, width=600, aspect=1.0, spp=1000, depth=50),
+    "c4": dict(name="final_scene 800x800, 5000 spp, depth 40", scene=8, width=800, aspect=1.0, spp=5000, depth=40,
+               earth_image="synthetic:6400x3200"),
+}
+SCENE_SEED = 1
+RENDER_SEED = 1
+
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (256 CU x 64 FMA/clk x 2 x 2.4 GHz); SURVEY.md Appendix B
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def algorithmic_work_per_sample(cnt):
+    """Algorithmic flops and bytes of one camera path, from the instrumented kernel's event counts
+    (DESIGN.md "Roofline": the per-event prices)."""
+    n = max(1, cnt["samples"])
+    per = {k: v / n for k, v in cnt.items()}
+    flops = (24 * per["node_visits"] + 30 * per["sphere_tests"] + 16 * per["quad_tests"] + 46 * per["rays"] +
+             1050 * per["noise_evals"] + 40)
+    bytes_ = (64 * per["node_visits"] + 64 * per["sphere_tests"] + 128 * per["quad_tests"] + 32 * per["medium_visits"] +
+              3 * per["image_lookups"])
+    return flops, bytes_, per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--bvh", default="reference", choices=["reference", "sah"])
+    ap.add_argument("--spp", type=int, default=0, help="override spp (smoke runs only: the JSON then names the reduced config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rt = importlib.import_module("rust-tracing_amd")
+    rtdist = importlib.import_module("rust-tracing_amd.dist")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rt.amd_lib().rt_device_count() <= local_rank:
+        raise SystemExit("bench.py: no HIP device for this rank; the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    wl_name = wl.pop("name")
+    if args.spp > 0:
+        wl["spp"] = args.spp
+        wl_name += f" [REDUCED to {args.spp} spp]"
+    hs = rt.HostScene(wl["scene"], scene_seed=SCENE_SEED, width=wl["width"], aspect=wl["aspect"], spp=wl["spp"],
+                      depth=wl["depth"], earth_image=wl.get("earth_image"), bvh=args.bvh)
+    w, h, spp = hs.width, hs.height, hs.camera.samples_per_pixel
+    scene = rt.DeviceScene(hs, device=local_rank)  # scene resident in HBM before timing
+
+    stream = torch.cuda.current_stream()
+    frame = torch.zeros(w * h * 3, dtype=torch.float64, device=dev)
+    if world > 1:
+        stride = rtdist.shard_stride(w, h, world)
+        tiles = torch.zeros(stride, dtype=torch.float64, device=dev)
+        gathered = torch.zeros(stride * world, dtype=torch.float64, device=dev) if rank == 0 else None
+        params = rt.render_params(seed=RENDER_SEED, shard_index=rank, shard_count=world, out_layout=rt.RT_OUT_TILES)
+    else:
+        params = rt.render_params(seed=RENDER_SEED)
+
+    kernel_ms = []
+
+    def step(timed):
+        ev0 = ev1 = None
+        if timed:
+            ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+        if world > 1:
+            scene.render_device(params, tiles.data_ptr(), stream.cuda_stream)
+        else:
+            scene.render_device(params, frame.data_ptr(), stream.cuda_stream)
+        if timed:
+            ev1.record(stream)
+        if world > 1:
+            rtdist.gather_tiles(tiles, gathered, rank, world)
+            if rank == 0:
+                rt.tiles_to_frame_device(w, h, world, gathered.data_ptr(), frame.data_ptr(), stream.cuda_stream)
+        return ev0, ev1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    events = [step(True) for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+
+    # --- outside the timed region: work counters (instrumented kernel, reduced spp), sanity, CPU baseline ---
+    result = None
+    if rank == 0:
+        cnt_spp = min(spp, 4)
+        scratch = torch.zeros(w * h * 3, dtype=torch.float64, device=dev)
+        cnt = scene.render_device_counted(rt.render_params(seed=RENDER_SEED, sample_end=cnt_spp), scratch.data_ptr(),
+                                          stream.cuda_stream)
+        flops_ps, bytes_ps, per = algorithmic_work_per_sample(cnt)
+        samples_per_launch = w * h * spp / world
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        tflops = flops_ps * samples_per_launch / (k_ms * 1e-3) / 1e12
+        gbs = bytes_ps * samples_per_launch / (k_ms * 1e-3) / 1e9
+        host_frame = frame.cpu().numpy()
+        assert np.isfinite(host_frame).all() and host_frame.max() > 0.0, "rendered frame is empty or not finite"
+
+        total_samples = float(w) * h * spp * args.steps
+        value = total_samples / elapsed / 1e6
+        traffic = None
+        tp = ROOT / "profiles" / "hbm_traffic.json"
+        if tp.exists():
+            try:
+                traffic = json.loads(tp.read_text()).get(args.workload, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Msamples/sec (pixels x spp / render seconds)", "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl_name, "scene_seed": SCENE_SEED, "render_seed": RENDER_SEED, "bvh": args.bvh,
+                       "width": w, "height": h, "spp": spp, "max_depth": hs.camera.max_depth,
+                       "parallelism": f"tiles{world}" if world > 1 else "single"},
+            "roofline": {
+                "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+                "kernel": "render_kernel<false>", "kernel_ms": round(k_ms, 3),
+                "algorithmic_flops_per_sample": round(flops_ps, 1), "algorithmic_bytes_per_sample": round(bytes_ps, 1),
+                "events_per_sample": {k: round(v, 3) for k, v in per.items() if k != "samples"},
+                "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 5)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, str(ROOT / "tests"))
+            import oracle_lib  # the CPU restatement: timed here as the baseline, never part of the product path
+            cores = oracle_lib.default_threads()
+            base_spp = 4 if args.workload in ("c2", "c3") else (10 if args.workload == "c1" else 1)
+            base_spp = min(base_spp, spp)
+            t1 = time.perf_counter()
+            oracle_lib.render(hs, rt.render_params(seed=RENDER_SEED, sample_end=base_spp), threads=cores)
+            dt = time.perf_counter() - t1
+            result["cpu_baseline"] = {
+                "value": round(w * h * base_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "sample": f"{w}x{h}, first {base_spp} of {spp} spp (cost is linear in spp), "
+                          f"reference-faithful mode (recursive, untightened box test), {dt:.1f} s"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -296,6 +296,17 @@ int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count,
 int rt_resolve_rgb8_device(int32_t width, int32_t height, int32_t spp, const double *d_frame_sum,
                            uint8_t *d_rgb8, void *hip_stream);
 
+/* Test hook: evaluates one of the device-side scalar functions of the normative arithmetic over host arrays
+ * (out[i] = f(a[i], b[i])), so that tests can compare the GPU's results with the oracle's bit for bit.
+ * For the two RNG ops, a[i] and b[i] carry the BIT PATTERNS of the 64-bit stream key and of the draw number
+ * (0-based, as in "draw n" of the RNG definition below). */
+typedef enum rt_debug_op {
+    RT_DEBUG_LOG = 1, RT_DEBUG_SIN = 2, RT_DEBUG_ACOS = 3, RT_DEBUG_ATAN2 = 4 /* atan2(a, b) */, RT_DEBUG_POW5 = 5,
+    RT_DEBUG_SQRT = 6, RT_DEBUG_DIV = 7 /* a / b */, RT_DEBUG_MUL_ADD = 8 /* a * b + a, two roundings */,
+    RT_DEBUG_RNG_RANDOM = 9, RT_DEBUG_RNG_RANGE = 10 /* gen_range(-1.0..1.0) */
+} rt_debug_op;
+int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device);
+
 const char *rt_last_error(void);
 const char *rt_version(void);
 

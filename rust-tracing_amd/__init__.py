@@ -177,9 +177,29 @@ RT_AMD_SYMBOLS = {
     "rt_out_size": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_tiles_to_frame_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_resolve_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_debug_eval": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double), C.c_int]),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
 }
+
+RT_DEBUG_LOG, RT_DEBUG_SIN, RT_DEBUG_ACOS, RT_DEBUG_ATAN2, RT_DEBUG_POW5, RT_DEBUG_SQRT, RT_DEBUG_DIV, \
+    RT_DEBUG_MUL_ADD, RT_DEBUG_RNG_RANDOM, RT_DEBUG_RNG_RANGE = range(1, 11)
+
+
+def debug_eval(op, a, b=None, device=0):
+    """rt_debug_eval: one device-side scalar function over arrays (test hook)."""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert b.shape == a.shape
+        bp = b.ctypes.data_as(C.POINTER(C.c_double))
+    _check(amd_lib().rt_debug_eval(op, a.size, a.ctypes.data_as(C.POINTER(C.c_double)), bp,
+                                   out.ctypes.data_as(C.POINTER(C.c_double)), device), "rt_debug_eval")
+    return out
 
 # every symbol include/rt_host.h declares
 RT_HOST_SYMBOLS = {
@@ -282,7 +302,11 @@ def render_params(*, seed=1, sample_begin=0, sample_end=0, max_depth=0, accumula
 
 
 def out_size(width, height, out_layout=RT_OUT_FRAME, shard_index=0, shard_count=1) -> int:
-    return int(amd_lib().rt_out_size(width, height, out_layout, shard_index, shard_count))
+    n = int(amd_lib().rt_out_size(width, height, out_layout, shard_index, shard_count))
+    if n < 0:
+        raise RtError(f"rt_out_size: invalid arguments (size {width}x{height}, layout {out_layout}, "
+                      f"shard {shard_index} of {shard_count})")
+    return n
 
 
 class DeviceScene:

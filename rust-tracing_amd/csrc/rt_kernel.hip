@@ -1,0 +1,1017 @@
+// rt_kernel.hip — the render megakernel for MI355X (gfx950) and the C ABI of include/rt_amd.h.
+//
+// One wavefront owns one 8x8 pixel tile at a time (lane = pixel); waves pull tiles from a device-side
+// counter until none are left, so the grid is sized to the machine, not to the image.  Per pixel and sample
+// a lane generates the camera ray (src/camera.rs:112-137), walks the threaded scene layout (rt_layout.h) —
+// box test, sphere / quad intersection, frame changes, constant media — shades the closest hit with the
+// reference's five materials and four textures (src/material.rs, src/texture.rs), and loops over bounces
+// (ray_color, src/renderer.rs:139-155, made iterative).  All arithmetic is f64 in the reference's operation
+// order with no FMA contraction, so the per-pixel sums equal the CPU restatement's bit for bit.
+//
+// There is no dense contraction anywhere on this path: no MFMA.  The bound is FP64 VALU issue under
+// divergence plus scene-data gathers (DESIGN.md "Roofline").
+#include "rt_amd.h"
+#include "rt_compile.hpp"
+#include "rt_device_math.h"
+#include "rt_layout.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace rtd;
+using namespace rtk;
+
+// =====================================================================================================
+// Device side
+// =====================================================================================================
+namespace {
+
+struct DMaterial { // 64 bytes
+    uint32_t kind;
+    uint32_t texture;
+    uint32_t needs_uv; // the texture below reads (u, v): only ImageTexture does (src/texture.rs:83)
+    uint32_t _pad;
+    double albedo[3];
+    double fuzz;
+    double ir;
+    double _pad2;
+};
+static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
+
+struct KParams {
+    const Node *nodes;
+    const Sphere *spheres;
+    const Quad *quads;
+    const Instance *insts;
+    const Medium *media;
+    const DMaterial *mats;
+    const rt_texture *texs;
+    const rt_perlin *perlins;
+    const ImageRef *images;
+    const uint8_t *texels;
+    const double *srgb_lut;
+    double *out;
+    double *att_stack;              // [max_depth][n_threads][3]: attenuations of the current path
+    uint32_t *tile_counter;
+    unsigned long long *counters;   // rt_counters as 10 u64, or null
+    rt_camera cam;
+    uint64_t seed_mixed;            // mix64(seed + gamma)
+    uint32_t n_nodes;
+    uint32_t n_threads;
+    int32_t sample_begin, sample_end, max_depth, accumulate;
+    int32_t shard_index, shard_count, out_layout;
+    int32_t tiles_x;
+    uint32_t n_local_tiles;
+};
+
+struct Counts {
+    uint32_t samples, rays, node_visits, sphere_tests, quad_tests, medium_visits, rng_draws, noise_evals,
+        image_lookups, instance_enters;
+};
+
+RT_DEV V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+RT_DEV V3 from(const rt_vec3 &a) { return V3{a.x, a.y, a.z}; }
+
+// ---- frame changes (Translate::hit then RotateY::hit, src/hittable.rs:96-106,:159-188) -------------------
+RT_DEV void apply_instance(const Instance &in, V3 &o, V3 &d) {
+    if (in.flags & INST_TRANSLATE) o = o - ld3(in.offset);
+    if (in.flags & INST_ROTATE) {
+        const double c = in.cos_theta, s = in.sin_theta;
+        const double ox = c * o.x - s * o.z, oz = s * o.x + c * o.z;
+        const double dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
+        o.x = ox; o.z = oz; d.x = dx; d.z = dz;
+    }
+}
+// world ray -> the frame of instance `inst` (outermost ancestor first); inst < 0: world frame
+RT_DEV void ray_to_frame(const Instance *insts, int32_t inst, V3 &o, V3 &d) {
+    if (inst < 0) return;
+    const uint32_t depth = insts[inst].depth;
+    for (uint32_t lv = 0; lv <= depth; ++lv) {
+        int32_t a = inst;
+        for (uint32_t k = depth; k > lv; --k) a = insts[a].parent;
+        apply_instance(insts[a], o, d);
+    }
+}
+// hit point and normal from the frame of `inst` back to the world (innermost first):
+// RotateY's output step (src/hittable.rs:173-182) then Translate's (src/hittable.rs:101)
+RT_DEV void hit_to_world(const Instance *insts, int32_t inst, V3 &p, V3 &n) {
+    while (inst >= 0) {
+        const Instance &in = insts[inst];
+        if (in.flags & INST_ROTATE) {
+            const double c = in.cos_theta, s = in.sin_theta;
+            const double px = c * p.x + s * p.z, pz = -s * p.x + c * p.z;
+            const double nx = c * n.x + s * n.z, nz = -s * n.x + c * n.z;
+            p.x = px; p.z = pz; n.x = nx; n.z = nz;
+        }
+        if (in.flags & INST_TRANSLATE) p = p + ld3(in.offset);
+        inst = in.parent;
+    }
+}
+
+// ---- random vectors (src/vec3.rs:54-88) ------------------------------------------------------------------
+template <bool COUNT> RT_DEV V3 random_in_unit_sphere(Rng &rng, Counts &cn) {
+    for (;;) {
+        const double x = rng.range(-1.0, 1.0);
+        const double y = rng.range(-1.0, 1.0);
+        const double z = rng.range(-1.0, 1.0);
+        if (COUNT) cn.rng_draws += 3;
+        const V3 p = v3(x, y, z);
+        if (len2(p) < 1.0) return p;
+    }
+}
+template <bool COUNT> RT_DEV V3 random_unit_vector(Rng &rng, Counts &cn) {
+    return normalize(random_in_unit_sphere<COUNT>(rng, cn));
+}
+
+// ---- Perlin (src/perlin.rs:27-64,:81-100) ----------------------------------------------------------------
+__device__ __noinline__ double perlin_noise(const rt_perlin *pn, V3 p) {
+    const int32_t i = f64_as_i32(__builtin_floor(p.x));
+    const int32_t j = f64_as_i32(__builtin_floor(p.y));
+    const int32_t k = f64_as_i32(__builtin_floor(p.z));
+    const double u = p.x - (double)i;
+    const double v = p.y - (double)j;
+    const double w = p.z - (double)k;
+    const double uu = u * u * (3.0 - 2.0 * u);
+    const double vv = v * v * (3.0 - 2.0 * v);
+    const double ww = w * w * (3.0 - 2.0 * w);
+    double acc = 0.0;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+        const int32_t px = pn->perm_x[(uint32_t)(i + di) & 255u];
+        // `i as FP * uu + (1 - i) as FP * (1 - uu)` is exactly uu (i = 1) or 1 - uu (i = 0)
+        const double fi = di ? uu : 1.0 - uu;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const int32_t py = pn->perm_y[(uint32_t)(j + dj) & 255u];
+            const double fj = dj ? vv : 1.0 - vv;
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const int32_t pz = pn->perm_z[(uint32_t)(k + dk) & 255u];
+                const double fk = dk ? ww : 1.0 - ww;
+                const V3 c = from(pn->ranvec[px ^ py ^ pz]);
+                const V3 weight_v = v3(u - (double)di, v - (double)dj, w - (double)dk);
+                acc += fi * fj * fk * dot(c, weight_v);
+            }
+        }
+    }
+    return acc;
+}
+RT_DEV double perlin_turbulence(const rt_perlin *pn, V3 p, int depth) {
+    double acc = 0.0;
+    double w = 1.0;
+    for (int d = 0; d < depth; ++d) {
+        acc += w * perlin_noise(pn, p);
+        w *= 0.5;
+        p = p * 2.0;
+    }
+    return __builtin_fabs(acc);
+}
+
+RT_DEV double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+// ---- Texture::value (src/texture.rs) ---------------------------------------------------------------------
+template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, uint32_t tex, double u, double v, V3 p, Counts &cn) {
+    const rt_texture *t = &P.texs[tex];
+    while (t->kind == RT_TEXTURE_CHECKER) { // src/texture.rs:59-69
+        const int32_t x = f64_as_i32(__builtin_floor(t->inv_scale * p.x));
+        const int32_t y = f64_as_i32(__builtin_floor(t->inv_scale * p.y));
+        const int32_t z = f64_as_i32(__builtin_floor(t->inv_scale * p.z));
+        const int32_t s = (int32_t)((uint32_t)x + (uint32_t)y + (uint32_t)z);
+        t = &P.texs[(s % 2 == 0) ? t->even : t->odd];
+    }
+    if (t->kind == RT_TEXTURE_SOLID) return from(t->color); // src/texture.rs:32-36
+    if (t->kind == RT_TEXTURE_IMAGE) {                      // src/texture.rs:82-92
+        if (COUNT) cn.image_lookups++;
+        const ImageRef im = P.images[t->image];
+        const double uc = clamp01(u);
+        const double vc = 1.0 - clamp01(v);
+        const uint32_t i = f64_as_u32(uc * (double)(im.width - 1u));
+        const uint32_t j = f64_as_u32(vc * (double)(im.height - 1u));
+        const uint8_t *px = P.texels + im.offset + ((size_t)j * im.width + i) * 3u;
+        return v3(P.srgb_lut[px[0]], P.srgb_lut[px[1]], P.srgb_lut[px[2]]);
+    }
+    // RT_TEXTURE_NOISE, src/texture.rs:107-110
+    if (COUNT) cn.noise_evals++;
+    const double turb = perlin_turbulence(&P.perlins[t->perlin], p, 7);
+    const double s = rt_sin(t->scale * p.z + 10.0 * turb) * 0.5 + 0.5;
+    return v3(s, s, s);
+}
+
+// ---- closest hit over the threaded layout ----------------------------------------------------------------
+struct Closest {
+    double t;
+    uint32_t prim; // PRIM_* | index, or PRIM_NONE
+    int32_t inst;  // frame the hit lives in
+};
+
+template <bool COUNT>
+RT_DEV Closest traverse(const KParams &P, const V3 wo, const V3 wd, const double time, Rng &rng, Counts &cn) {
+    const double INF = __builtin_inf();
+    V3 o = wo, d = wd;
+    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); // AABB::hit divides per visit (src/aabb.rs:66): same quotient
+    double a = len2(d);                           // Sphere::hit's `a` (src/sphere.rs:66)
+    int32_t cur_inst = -1;
+
+    Closest best{INF, PRIM_NONE, -1};
+    // the interval box tests and primitive tests run against: ray_color's (0.001, closest so far)
+    // (src/renderer.rs:144) or, inside a ConstantMedium, the boundary query's own interval
+    double cur_tmin = 0.001, cur_tmax = INF;
+    // ConstantMedium state (src/constant_medium.rs:33-71): 0 = not in a medium, 1 = first boundary query, 2 = second
+    uint32_t mode = 0;
+    bool sub_hit = false;
+    double med_t1 = 0.0;
+
+    uint32_t node = 0;
+    while (node < P.n_nodes) {
+        const Node *np = &P.nodes[node];
+        const uint32_t kflags = np->kind;
+        const uint32_t skip = np->skip;
+        if (!(kflags & NODE_NO_BBOX)) {
+            if (COUNT) cn.node_visits++;
+            // slab test, interval narrowed axis by axis (see DESIGN.md "Box test" for why this cannot change a
+            // result relative to the reference's un-narrowed test)
+            double tmin = cur_tmin, tmax = cur_tmax;
+            bool miss = false;
+            {
+                double t0 = (np->lo[0] - o.x) * inv.x, t1 = (np->hi[0] - o.x) * inv.x;
+                if (inv.x < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+                tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
+                miss = tmax <= tmin;
+            }
+            if (!miss) {
+                double t0 = (np->lo[1] - o.y) * inv.y, t1 = (np->hi[1] - o.y) * inv.y;
+                if (inv.y < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+                tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
+                miss = tmax <= tmin;
+            }
+            if (!miss) {
+                double t0 = (np->lo[2] - o.z) * inv.z, t1 = (np->hi[2] - o.z) * inv.z;
+                if (inv.z < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+                tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
+                miss = tmax <= tmin;
+            }
+            if (miss) { node = skip; continue; }
+        }
+        const uint32_t kind = kflags & NODE_KIND_MASK;
+        const uint32_t na = np->a, nb = np->b;
+        if (kind == NK_INNER) {
+            node = node + 1;
+        } else if (kind == NK_SPHERES) {
+            for (uint32_t q = na; q < na + nb; ++q) { // Sphere::hit, src/sphere.rs:58-83
+                if (COUNT) cn.sphere_tests++;
+                const Sphere *s = &P.spheres[q];
+                V3 center = ld3(s->center);
+                if (s->is_moving) center = center + ld3(s->center_vec) * time;
+                const V3 oc = o - center;
+                const double half_b = dot(oc, d);
+                const double c = len2(oc) - s->radius * s->radius;
+                const double discriminant = half_b * half_b - a * c;
+                if (discriminant < 0.0) continue;
+                const double sqrtd = __builtin_sqrt(discriminant);
+                double root = (-half_b - sqrtd) / a;
+                if (!(cur_tmin < root && root < cur_tmax)) {
+                    root = (-half_b + sqrtd) / a;
+                    if (!(cur_tmin < root && root < cur_tmax)) continue;
+                }
+                cur_tmax = root;
+                if (mode == 0) { best.t = root; best.prim = PRIM_SPHERE | q; best.inst = cur_inst; }
+                else sub_hit = true;
+            }
+            node = skip;
+        } else if (kind == NK_QUADS) {
+            for (uint32_t q = na; q < na + nb; ++q) { // Quad::hit, src/quad.rs:96-127
+                if (COUNT) cn.quad_tests++;
+                const Quad *qd = &P.quads[q];
+                const V3 normal = ld3(qd->normal);
+                const double denom = dot(normal, d);
+                if (__builtin_fabs(denom) < 1e-8) continue;
+                const double t = (qd->d - dot(normal, o)) / denom;
+                if (!(cur_tmin <= t && t <= cur_tmax)) continue;
+                const V3 intersection = o + d * t;
+                const V3 php = intersection - ld3(qd->q);
+                const V3 w = ld3(qd->w);
+                const double alpha = dot(w, cross(php, ld3(qd->v)));
+                const double beta = dot(w, cross(ld3(qd->u), php));
+                if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
+                cur_tmax = t;
+                if (mode == 0) { best.t = t; best.prim = PRIM_QUAD | q; best.inst = cur_inst; }
+                else sub_hit = true;
+            }
+            node = skip;
+        } else if (kind == NK_INST_ENTER) {
+            if (COUNT) cn.instance_enters++;
+            apply_instance(P.insts[na], o, d);
+            inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            a = len2(d);
+            cur_inst = (int32_t)na;
+            node = node + 1;
+        } else if (kind == NK_INST_EXIT) {
+            cur_inst = P.insts[na].parent;
+            o = wo; d = wd;
+            ray_to_frame(P.insts, cur_inst, o, d);
+            inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+            a = len2(d);
+            node = node + 1;
+        } else if (kind == NK_MEDIUM_ENTER) {
+            // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
+            if (COUNT) cn.medium_visits++;
+            mode = 1;
+            sub_hit = false;
+            cur_tmin = -INF;
+            cur_tmax = INF;
+            node = node + 1;
+        } else { // NK_MEDIUM_EXIT
+            bool again = false;
+            if (mode == 1) {
+                if (sub_hit) { // boundary.hit(r, (hit1.t + 0.0001, inf)) (src/constant_medium.rs:36-38)
+                    med_t1 = cur_tmax;
+                    mode = 2;
+                    sub_hit = false;
+                    cur_tmin = med_t1 + 0.0001;
+                    cur_tmax = INF;
+                    again = true;
+                }
+            } else if (sub_hit) { // src/constant_medium.rs:40-61
+                double h1 = __builtin_fmax(med_t1, 0.001);
+                const double h2 = __builtin_fmin(cur_tmax, best.t);
+                if (h1 < h2) {
+                    h1 = __builtin_fmax(h1, 0.0);
+                    const double ray_length = __builtin_sqrt(len2(d));
+                    const double distance_inside_boundary = (h2 - h1) * ray_length;
+                    if (COUNT) cn.rng_draws++;
+                    const double hit_distance = P.media[na].neg_inv_density * rt_log(rng.random());
+                    if (hit_distance <= distance_inside_boundary) {
+                        best.t = h1 + hit_distance / ray_length;
+                        best.prim = PRIM_MEDIUM | na;
+                        best.inst = cur_inst;
+                    }
+                }
+            }
+            if (again) {
+                node = nb;
+            } else {
+                mode = 0;
+                cur_tmin = 0.001;
+                cur_tmax = best.t;
+                node = node + 1;
+            }
+        }
+    }
+    return best;
+}
+
+// ---- one camera path: Camera::get_ray + ray_color ---------------------------------------------------------
+template <bool COUNT>
+RT_DEV V3 trace_sample(const KParams &P, const int32_t i, const int32_t j, Rng &rng, const uint32_t gtid, Counts &cn) {
+    const rt_camera &cam = P.cam;
+    // Camera::get_ray (src/camera.rs:112-137)
+    const V3 du = from(cam.pixel_delta_u), dv = from(cam.pixel_delta_v);
+    const V3 pixel_center = from(cam.pixel00_loc) + du * (double)i + dv * (double)j;
+    const double px = -0.5 + rng.random();
+    const double py = -0.5 + rng.random();
+    if (COUNT) cn.rng_draws += 2;
+    const V3 pixel_sample = pixel_center + (du * px + dv * py);
+    V3 ro;
+    if (cam.defocus_angle <= 0.0) {
+        ro = from(cam.center);
+    } else { // random_in_unit_disk (src/vec3.rs:77-88)
+        double dx, dy;
+        for (;;) {
+            dx = rng.range(-1.0, 1.0);
+            dy = rng.range(-1.0, 1.0);
+            if (COUNT) cn.rng_draws += 2;
+            if (dx * dx + dy * dy + 0.0 * 0.0 < 1.0) break;
+        }
+        ro = from(cam.center) + from(cam.defocus_disk_u) * dx + from(cam.defocus_disk_v) * dy;
+    }
+    V3 rd = pixel_sample - ro;
+    const double time = rng.random();
+    if (COUNT) cn.rng_draws += 1;
+
+    // ray_color (src/renderer.rs:139-155), iteratively.  In this codebase a material that scatters emits
+    // nothing and the one that emits never scatters, so the recursion unrolls to
+    //     A_1 * (A_2 * ( ... (A_n * terminal)))
+    // evaluated innermost first; the attenuations are parked in att_stack and multiplied back in that order.
+    int32_t depth = P.max_depth;
+    uint32_t n_att = 0;
+    V3 result = v3(0.0, 0.0, 0.0);
+    double *att = P.att_stack + (size_t)gtid * 3u;
+    const size_t att_stride = (size_t)P.n_threads * 3u;
+
+    for (;;) {
+        if (depth <= 0) break; // Color::ZERO
+        if (COUNT) cn.rays++;
+        const Closest hit = traverse<COUNT>(P, ro, rd, time, rng, cn);
+        if (hit.prim == PRIM_NONE) { result = from(cam.background); break; }
+
+        // rebuild the HitRecord of the closest hit in its own frame, then carry it to the world
+        V3 lo = ro, ld = rd;
+        ray_to_frame(P.insts, hit.inst, lo, ld);
+        V3 p = lo + ld * hit.t; // Ray::at (src/ray.rs:30-32)
+        V3 outward_normal;
+        uint32_t mat;
+        double u = 0.0, v = 0.0;
+        const uint32_t pk = hit.prim & PRIM_KIND_MASK, pi = hit.prim & PRIM_INDEX_MASK;
+        bool uv_from_sphere = false;
+        if (pk == PRIM_SPHERE) { // src/sphere.rs:85-88
+            const Sphere *s = &P.spheres[pi];
+            V3 center = ld3(s->center);
+            if (s->is_moving) center = center + ld3(s->center_vec) * time;
+            outward_normal = div(p - center, s->radius);
+            mat = s->material;
+            uv_from_sphere = true;
+        } else if (pk == PRIM_QUAD) { // src/quad.rs:118-132
+            const Quad *qd = &P.quads[pi];
+            outward_normal = ld3(qd->normal);
+            mat = qd->material;
+            if (P.mats[mat].needs_uv) {
+                const V3 php = p - ld3(qd->q);
+                const V3 w = ld3(qd->w);
+                u = dot(w, cross(php, ld3(qd->v)));
+                v = dot(w, cross(ld3(qd->u), php));
+            }
+        } else { // ConstantMedium: normal := r.direction (src/constant_medium.rs:52-58)
+            outward_normal = ld;
+            mat = P.media[pi].phase_material;
+        }
+        const DMaterial *m = &P.mats[mat];
+        if (uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
+            const double PI = 3.14159265358979323846264338327950288;
+            const double theta = rt_acos(-outward_normal.y);
+            const double phi = rt_atan2(-outward_normal.z, outward_normal.x) + PI;
+            u = phi / (2.0 * PI);
+            v = theta / PI;
+        }
+        // HitRecord::new (src/hittable.rs:22-37)
+        const bool front_face = dot(ld, outward_normal) < 0.0;
+        V3 normal = front_face ? outward_normal : -outward_normal;
+        hit_to_world(P.insts, hit.inst, p, normal);
+
+        const uint32_t mk = m->kind;
+        // Every material that reads a texture reads exactly one, after its random draws (which textures never
+        // make): evaluate it at one place.  Likewise the unit-sphere rejection sample (src/vec3.rs:54-61) is
+        // the first draw of Lambertian, Metal and Isotropic alike.
+        V3 tex = v3(1.0, 1.0, 1.0);
+        V3 rs = v3(0.0, 0.0, 0.0);
+        if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
+        if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) tex = texture_value<COUNT>(P, m->texture, u, v, p, cn);
+        if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
+            result = tex;
+            break;
+        }
+        V3 attenuation = tex;
+        bool unit_attenuation = false;
+        V3 new_dir;
+        if (mk == RT_MATERIAL_LAMBERTIAN) { // src/material.rs:26-42
+            const V3 scatter_direction = normal + normalize(rs);
+            new_dir = near_zero(scatter_direction) ? normal : scatter_direction;
+        } else if (mk == RT_MATERIAL_METAL) { // src/material.rs:53-64
+            const V3 refl = reflect(normalize(rd), normal);
+            const V3 reflected = refl + rs * m->fuzz;
+            if (!(dot(reflected, normal) > 0.0)) break; // absorbed: emission (zero) only
+            new_dir = reflected;
+            attenuation = ld3(m->albedo);
+        } else if (mk == RT_MATERIAL_DIELECTRIC) { // src/material.rs:80-104
+            const double refraction_ratio = front_face ? 1.0 / m->ir : m->ir;
+            const V3 unit_direction = normalize(rd);
+            const double cos_theta = __builtin_fmin(dot(-unit_direction, normal), 1.0);
+            const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+            bool do_reflect = refraction_ratio * sin_theta > 1.0;
+            if (!do_reflect) { // `||` short-circuit: draw only when refraction is possible
+                double r0 = (1.0 - refraction_ratio) / (1.0 + refraction_ratio);
+                r0 = r0 * r0;
+                const double reflectance = r0 + (1.0 - r0) * rt_pow5(1.0 - cos_theta);
+                if (COUNT) cn.rng_draws++;
+                do_reflect = reflectance > rng.random();
+            }
+            new_dir = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
+            unit_attenuation = true; // Color::ONE: multiplying by it is the identity, nothing to park
+        } else { // RT_MATERIAL_ISOTROPIC, src/material.rs:132-138
+            new_dir = normalize(rs);
+        }
+        if (!unit_attenuation) {
+            double *slot = att + (size_t)n_att * att_stride;
+            slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
+            n_att++;
+        }
+        ro = p;
+        rd = new_dir;
+        depth--;
+    }
+    // attenuation * ray_color(...), innermost first.  A zero terminal stays zero (attenuations are finite).
+    if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
+        while (n_att > 0) {
+            n_att--;
+            const double *slot = att + (size_t)n_att * att_stride;
+            result = v3(slot[0], slot[1], slot[2]) * result;
+        }
+    }
+    return result;
+}
+
+template <bool COUNT> __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t w = P.cam.image_width, h = P.cam.image_height;
+    Counts cn{};
+    Rng rng;
+
+    for (;;) {
+        // the wave takes the next tile of this shard
+        uint32_t lt = 0;
+        if (lane == 0) lt = atomicAdd(P.tile_counter, 1u);
+        lt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lt);
+        if (lt >= P.n_local_tiles) break;
+        const uint32_t k = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
+        const int32_t i = (int32_t)(k % (uint32_t)P.tiles_x) * RT_TILE_W + (int32_t)(lane & 7u);
+        const int32_t j = (int32_t)(k / (uint32_t)P.tiles_x) * RT_TILE_H + (int32_t)(lane >> 3);
+        const bool valid = i < w && j < h;
+        double *dst = nullptr;
+        if (P.out_layout == RT_OUT_TILES) dst = P.out + ((size_t)lt * 64u + lane) * 3u;
+        else if (valid) dst = P.out + ((size_t)j * (size_t)w + (size_t)i) * 3u;
+        if (!valid) {
+            if (dst) { dst[0] = 0.0; dst[1] = 0.0; dst[2] = 0.0; }
+            continue;
+        }
+        V3 acc = v3(0.0, 0.0, 0.0);
+        if (P.accumulate) acc = v3(dst[0], dst[1], dst[2]);
+        const uint32_t pixel = (uint32_t)j * (uint32_t)w + (uint32_t)i; // screen_pos (src/renderer.rs:32-33)
+        for (int32_t s = P.sample_begin; s < P.sample_end; ++s) {      // src/renderer.rs:35-40
+            rng.start(P.seed_mixed, pixel, (uint32_t)s);
+            const V3 c = trace_sample<COUNT>(P, i, j, rng, gtid, cn);
+            acc = acc + c;
+            if (COUNT) cn.samples++;
+        }
+        dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+    }
+
+    if (COUNT && P.counters) {
+        const uint32_t vals[10] = {cn.samples, cn.rays, cn.node_visits, cn.sphere_tests, cn.quad_tests,
+                                   cn.medium_visits, cn.rng_draws, cn.noise_evals, cn.image_lookups,
+                                   cn.instance_enters};
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            unsigned long long v = vals[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&P.counters[q], v);
+        }
+    }
+}
+
+// frame-end reassembly: [shard][local tile][64][3] -> row-major frame
+__global__ void tiles_to_frame_kernel(int32_t w, int32_t h, int32_t tiles_x, int32_t shard_count, int64_t shard_stride,
+                                      const double *__restrict__ gathered, double *__restrict__ frame) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per pixel
+    if (idx >= (int64_t)w * h) return;
+    const int32_t i = (int32_t)(idx % w), j = (int32_t)(idx / w);
+    const int64_t k = (int64_t)(j / RT_TILE_H) * tiles_x + (i / RT_TILE_W);
+    const int64_t shard = k % shard_count, lt = k / shard_count;
+    const int64_t src = shard * shard_stride + ((lt * RT_TILE_H + (j % RT_TILE_H)) * RT_TILE_W + (i % RT_TILE_W)) * 3;
+    frame[idx * 3 + 0] = gathered[src + 0];
+    frame[idx * 3 + 1] = gathered[src + 1];
+    frame[idx * 3 + 2] = gathered[src + 2];
+}
+
+// color_to_rgb(c / spp) (src/renderer.rs:55-58, src/color.rs:12-19)
+__global__ void resolve_rgb8_kernel(int64_t n_values, double inv_spp, const double *__restrict__ sum, uint8_t *__restrict__ rgb) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_values) return;
+    const double g = pow(sum[idx] * inv_spp, 1.0 / 2.2);
+    uint8_t b = 0;
+    if (g == g) {
+        const double c = g < 0.0 ? 0.0 : (g > 0.999 ? 0.999 : g);
+        b = (uint8_t)(256.0 * c);
+    }
+    rgb[idx] = b;
+}
+
+// test hook: evaluates one device-side scalar function over arrays (rt_debug_eval)
+__global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                  double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double x = a[idx], y = b ? b[idx] : 0.0;
+    double r = 0.0;
+    switch (op) {
+    case RT_DEBUG_LOG: r = rt_log(x); break;
+    case RT_DEBUG_SIN: r = rt_sin(x); break;
+    case RT_DEBUG_ACOS: r = rt_acos(x); break;
+    case RT_DEBUG_ATAN2: r = rt_atan2(x, y); break;
+    case RT_DEBUG_POW5: r = rt_pow5(x); break;
+    case RT_DEBUG_SQRT: r = __builtin_sqrt(x); break;
+    case RT_DEBUG_DIV: r = x / y; break;
+    case RT_DEBUG_MUL_ADD: r = x * y + x; break; // must be two roundings (no contraction)
+    case RT_DEBUG_RNG_RANDOM: { // x, y carry the key's and the draw number's bits
+        Rng g; g.state = f2u(x) + (f2u(y) ) * RNG_GAMMA; r = g.random(); break;
+    }
+    case RT_DEBUG_RNG_RANGE: {
+        Rng g; g.state = f2u(x) + (f2u(y)) * RNG_GAMMA; r = g.range(-1.0, 1.0); break;
+    }
+    default: r = 0.0;
+    }
+    out[idx] = r;
+}
+
+} // namespace
+
+// =====================================================================================================
+// Host side: the C ABI
+// =====================================================================================================
+namespace {
+
+thread_local std::string g_last_error;
+
+uint64_t rtk_host_mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+int fail(int status, const std::string &msg) {
+    g_last_error = msg;
+    return status;
+}
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                         \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                    \
+    } while (0)
+
+struct Workspace {
+    double *att_stack = nullptr;
+    size_t att_bytes = 0;
+    uint32_t *tile_counter = nullptr;
+    unsigned long long *counters = nullptr;
+};
+
+template <class T> struct DeviceArray {
+    T *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    int n_cus = 0;
+    int blocks_per_cu[2] = {0, 0}; // plain / counted kernel
+    DeviceArray<Node> nodes;
+    DeviceArray<Sphere> spheres;
+    DeviceArray<Quad> quads;
+    DeviceArray<Instance> insts;
+    DeviceArray<Medium> media;
+    DeviceArray<DMaterial> mats;
+    DeviceArray<rt_texture> texs;
+    DeviceArray<rt_perlin> perlins;
+    DeviceArray<ImageRef> images;
+    DeviceArray<uint8_t> texels;
+    DeviceArray<double> lut;
+    uint32_t n_nodes = 0;
+    rt_scene_stats stats{};
+    std::mutex mu;
+    std::map<hipStream_t, Workspace> workspaces; // one per stream: launches on a stream are ordered
+    std::mutex host_render_mu;                   // rt_render (host-buffer form) calls on one scene run one at a time
+};
+
+namespace {
+
+template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
+    dst.bytes = src.size() * sizeof(T);
+    // never hand the kernel a null table: allocate at least one element
+    const size_t alloc = dst.bytes ? dst.bytes : sizeof(T);
+    HIP_TRY(hipMalloc((void **)&dst.ptr, alloc));
+    if (dst.bytes) HIP_TRY(hipMemcpy(dst.ptr, src.data(), dst.bytes, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(dst.ptr, 0, alloc));
+    return RT_OK;
+}
+
+bool texture_needs_uv(const std::vector<rt_texture> &texs, int32_t t, int depth = 0) {
+    if (t < 0 || depth > 16) return false;
+    const rt_texture &x = texs[(size_t)t];
+    if (x.kind == RT_TEXTURE_IMAGE) return true;
+    if (x.kind == RT_TEXTURE_CHECKER) return texture_needs_uv(texs, x.even, depth + 1) || texture_needs_uv(texs, x.odd, depth + 1);
+    return false;
+}
+
+void free_scene(rt_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (auto &kv : s->workspaces) {
+        (void)hipFree(kv.second.att_stack);
+        (void)hipFree(kv.second.tile_counter);
+        (void)hipFree(kv.second.counters);
+    }
+    (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
+    (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr);
+    delete s;
+}
+
+int64_t tiles_total(int32_t w, int32_t h) {
+    return (int64_t)((w + RT_TILE_W - 1) / RT_TILE_W) * ((h + RT_TILE_H - 1) / RT_TILE_H);
+}
+int64_t tiles_local(int32_t w, int32_t h, int32_t shard_index, int32_t shard_count) {
+    return (tiles_total(w, h) - shard_index + shard_count - 1) / shard_count;
+}
+
+int normalise_params(const rt_camera *cam, rt_render_params &p) {
+    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty image");
+    if ((int64_t)cam->image_width * cam->image_height > 0x7fffffffll)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: image has more than 2^31 pixels");
+    if (p.sample_end <= 0) p.sample_end = cam->samples_per_pixel;
+    if (p.max_depth <= 0) p.max_depth = cam->max_depth;
+    if (p.shard_count <= 0) p.shard_count = 1;
+    if (p.sample_begin < 0 || p.sample_end < p.sample_begin) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: bad sample range");
+    if (p.shard_index < 0 || p.shard_index >= p.shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: shard_index out of range");
+    if (p.out_layout != RT_OUT_FRAME && p.out_layout != RT_OUT_TILES) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: unknown out_layout");
+    if (p.max_depth <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: max_depth must be positive");
+    return RT_OK;
+}
+
+int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, double *d_out, hipStream_t stream,
+                  rt_counters *out_counters) {
+    int rc = normalise_params(camera, p);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    const bool counted = out_counters != nullptr;
+    const int64_t n_local = tiles_local(camera->image_width, camera->image_height, p.shard_index, p.shard_count);
+    if (n_local <= 0) {
+        if (out_counters) *out_counters = rt_counters{};
+        return RT_OK;
+    }
+
+    const int threads = 256;
+    const int bpc = scene->blocks_per_cu[counted ? 1 : 0];
+    int64_t grid = (n_local + 3) / 4; // 4 waves per block, one tile per wave at a time
+    const int64_t resident = (int64_t)scene->n_cus * bpc;
+    if (grid > resident) grid = resident;
+    if (grid < 1) grid = 1;
+    const uint32_t n_threads = (uint32_t)(grid * threads);
+
+    Workspace ws;
+    {
+        std::lock_guard<std::mutex> lock(scene->mu);
+        Workspace &w = scene->workspaces[stream];
+        const size_t need = (size_t)p.max_depth * n_threads * 3u * sizeof(double);
+        if (w.att_bytes < need) {
+            if (w.att_stack) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipFree(w.att_stack));
+                w.att_stack = nullptr;
+                w.att_bytes = 0;
+            }
+            HIP_TRY(hipMalloc((void **)&w.att_stack, need));
+            w.att_bytes = need;
+        }
+        if (!w.tile_counter) HIP_TRY(hipMalloc((void **)&w.tile_counter, sizeof(uint32_t)));
+        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 10 * sizeof(unsigned long long)));
+        ws = w;
+    }
+    HIP_TRY(hipMemsetAsync(ws.tile_counter, 0, sizeof(uint32_t), stream));
+    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 10 * sizeof(unsigned long long), stream));
+
+    KParams K{};
+    K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
+    K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
+    K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
+    K.out = d_out;
+    K.att_stack = ws.att_stack;
+    K.tile_counter = ws.tile_counter;
+    K.counters = counted ? ws.counters : nullptr;
+    K.cam = *camera;
+    K.seed_mixed = rtk_host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
+    K.n_nodes = scene->n_nodes;
+    K.n_threads = n_threads;
+    K.sample_begin = p.sample_begin; K.sample_end = p.sample_end; K.max_depth = p.max_depth; K.accumulate = p.accumulate;
+    K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
+    K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
+    K.n_local_tiles = (uint32_t)n_local;
+
+    if (counted) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
+    HIP_TRY(hipGetLastError());
+
+    if (counted) {
+        unsigned long long host[10];
+        HIP_TRY(hipMemcpyAsync(host, ws.counters, sizeof host, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        out_counters->samples = host[0]; out_counters->rays = host[1]; out_counters->node_visits = host[2];
+        out_counters->sphere_tests = host[3]; out_counters->quad_tests = host[4]; out_counters->medium_visits = host[5];
+        out_counters->rng_draws = host[6]; out_counters->noise_evals = host[7]; out_counters->image_lookups = host[8];
+        out_counters->instance_enters = host[9];
+    }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+const char *rt_version(void) { return "rt_amd 0.1 (gfx950, abi 1)"; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t rt_out_size(int32_t width, int32_t height, int32_t out_layout, int32_t shard_index, int32_t shard_count) {
+    if (width <= 0 || height <= 0) return -1;
+    if (shard_count <= 0) shard_count = 1;
+    if (shard_index < 0 || shard_index >= shard_count) return -1;
+    if (out_layout == RT_OUT_FRAME) return (int64_t)width * height * 3;
+    if (out_layout == RT_OUT_TILES) return tiles_local(width, height, shard_index, shard_count) * RT_TILE_W * RT_TILE_H * 3;
+    return -1;
+}
+
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) {
+    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
+    *out_scene = nullptr;
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_scene_create: ") + e.what());
+    }
+    const int ndev = rt_device_count();
+    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    rt_scene *s = new rt_scene();
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "hipGetDeviceProperties failed"); }
+    s->n_cus = prop.multiProcessorCount;
+    int b0 = 0, b1 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, render_kernel<false>, 256, 0) != hipSuccess || b0 < 1) b0 = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, render_kernel<true>, 256, 0) != hipSuccess || b1 < 1) b1 = 1;
+    s->blocks_per_cu[0] = b0;
+    s->blocks_per_cu[1] = b1;
+
+    std::vector<DMaterial> mats(cs.materials.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const rt_material &m = cs.materials[i];
+        DMaterial d{};
+        d.kind = (uint32_t)m.kind;
+        d.texture = m.texture >= 0 ? (uint32_t)m.texture : 0u;
+        d.needs_uv = texture_needs_uv(cs.textures, m.texture) ? 1u : 0u;
+        d.albedo[0] = m.albedo.x; d.albedo[1] = m.albedo.y; d.albedo[2] = m.albedo.z;
+        d.fuzz = m.fuzz;
+        d.ir = m.ir;
+        mats[i] = d;
+    }
+
+    int rc = RT_OK;
+    if ((rc = upload(s->nodes, cs.nodes)) != RT_OK || (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
+        (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
+        (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
+        (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
+        (rc = upload(s->images, cs.images)) != RT_OK || (rc = upload(s->texels, cs.texels)) != RT_OK ||
+        (rc = upload(s->lut, cs.srgb_lut)) != RT_OK) {
+        free_scene(s);
+        return rc;
+    }
+    s->n_nodes = (uint32_t)cs.nodes.size();
+    rt_scene_stats &st = s->stats;
+    st.node_bytes = s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
+    st.instance_bytes = s->insts.bytes; st.medium_bytes = s->media.bytes; st.material_bytes = s->mats.bytes;
+    st.texture_bytes = s->texs.bytes; st.perlin_bytes = s->perlins.bytes; st.image_bytes = s->texels.bytes;
+    st.n_nodes = (uint32_t)cs.nodes.size(); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
+    st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
+    st.max_instance_depth = cs.max_instance_depth;
+    st.lds_nodes = 0; st.lds_bytes = 0;
+    *out_scene = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *scene) { free_scene(scene); }
+
+int rt_scene_get_stats(const rt_scene *scene, rt_scene_stats *out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_get_stats: null argument");
+    *out = scene->stats;
+    return RT_OK;
+}
+
+int rt_render_device(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params, double *d_out_rgb_sum,
+                     void *hip_stream) {
+    if (!scene || !camera || !params || !d_out_rgb_sum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null argument");
+    return launch_render(const_cast<rt_scene *>(scene), camera, *params, d_out_rgb_sum, (hipStream_t)hip_stream, nullptr);
+}
+
+int rt_render_device_counted(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
+                             double *d_out_rgb_sum, void *hip_stream, rt_counters *out_counters) {
+    if (!scene || !camera || !params || !d_out_rgb_sum || !out_counters)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_counted: null argument");
+    return launch_render(const_cast<rt_scene *>(scene), camera, *params, d_out_rgb_sum, (hipStream_t)hip_stream, out_counters);
+}
+
+int rt_render(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params, double *out_rgb_sum) {
+    if (!scene || !camera || !params || !out_rgb_sum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
+    rt_render_params p = *params;
+    int rc = normalise_params(camera, p);
+    if (rc != RT_OK) return rc;
+    rt_scene *s = const_cast<rt_scene *>(scene);
+    std::lock_guard<std::mutex> serial(s->host_render_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    const int32_t w = camera->image_width, h = camera->image_height;
+    // on the device the shard always renders into its compact tile buffer; the requested layout is produced on the host
+    rt_render_params dp = p;
+    dp.out_layout = RT_OUT_TILES;
+    const int64_t n_tiles_vals = rt_out_size(w, h, RT_OUT_TILES, p.shard_index, p.shard_count);
+    if (n_tiles_vals <= 0) return RT_OK;
+    const int32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
+    const int64_t n_local = n_tiles_vals / (RT_TILE_W * RT_TILE_H * 3);
+    std::vector<double> tiles((size_t)n_tiles_vals);
+    auto for_each_pixel = [&](auto &&fn) {
+        for (int64_t lt = 0; lt < n_local; ++lt) {
+            const int64_t k = lt * p.shard_count + p.shard_index;
+            const int32_t x0 = (int32_t)(k % tiles_x) * RT_TILE_W, y0 = (int32_t)(k / tiles_x) * RT_TILE_H;
+            for (int32_t ty = 0; ty < RT_TILE_H; ++ty)
+                for (int32_t tx = 0; tx < RT_TILE_W; ++tx) {
+                    const int32_t i = x0 + tx, j = y0 + ty;
+                    if (i >= w || j >= h) continue;
+                    fn(&tiles[(size_t)((lt * RT_TILE_H + ty) * RT_TILE_W + tx) * 3u], ((size_t)j * w + i) * 3u);
+                }
+        }
+    };
+    if (p.accumulate) { // seed the device buffer with the caller's running sums
+        if (p.out_layout == RT_OUT_TILES) std::copy(out_rgb_sum, out_rgb_sum + n_tiles_vals, tiles.begin());
+        else for_each_pixel([&](double *t, size_t f) { t[0] = out_rgb_sum[f]; t[1] = out_rgb_sum[f + 1]; t[2] = out_rgb_sum[f + 2]; });
+    }
+    double *d_tiles = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_tiles, (size_t)n_tiles_vals * sizeof(double)));
+    hipStream_t stream = nullptr;
+    rc = RT_OK;
+    do {
+        if (p.accumulate && hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_render: upload of running sums failed");
+            break;
+        }
+        rc = launch_render(s, camera, dp, d_tiles, stream, nullptr);
+        if (rc != RT_OK) break;
+        hipError_t e = hipMemcpy(tiles.data(), d_tiles, tiles.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(RT_ERR_HIP, std::string("rt_render: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    (void)hipFree(d_tiles);
+    if (rc != RT_OK) return rc;
+    if (p.out_layout == RT_OUT_TILES) std::copy(tiles.begin(), tiles.end(), out_rgb_sum);
+    else for_each_pixel([&](double *t, size_t f) { out_rgb_sum[f] = t[0]; out_rgb_sum[f + 1] = t[1]; out_rgb_sum[f + 2] = t[2]; });
+    return RT_OK;
+}
+
+int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count, const double *d_gathered, double *d_frame,
+                             void *hip_stream) {
+    if (!d_gathered || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_tiles_to_frame_device: bad argument");
+    const int64_t n = (int64_t)width * height;
+    const int64_t stride = rt_out_size(width, height, RT_OUT_TILES, 0, shard_count);
+    const int32_t tiles_x = (width + RT_TILE_W - 1) / RT_TILE_W;
+    hipLaunchKernelGGL(tiles_to_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, width,
+                       height, tiles_x, shard_count, stride, d_gathered, d_frame);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device) {
+    if (n <= 0 || !a || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_eval: bad argument");
+    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_eval: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    int rc = RT_OK;
+    do {
+        if (hipMalloc((void **)&da, bytes) != hipSuccess || hipMalloc((void **)&dout, bytes) != hipSuccess ||
+            (b && hipMalloc((void **)&db, bytes) != hipSuccess)) { rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_eval: hipMalloc failed"); break; }
+        if (hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            (b && hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) != hipSuccess)) { rc = fail(RT_ERR_HIP, "rt_debug_eval: upload failed"); break; }
+        hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, da, db, dout);
+        hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(RT_ERR_HIP, std::string("rt_debug_eval: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+}
+
+int rt_resolve_rgb8_device(int32_t width, int32_t height, int32_t spp, const double *d_frame_sum, uint8_t *d_rgb8, void *hip_stream) {
+    if (!d_frame_sum || !d_rgb8 || width <= 0 || height <= 0 || spp <= 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_resolve_rgb8_device: bad argument");
+    const int64_t n = (int64_t)width * height * 3;
+    hipLaunchKernelGGL(resolve_rgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n,
+                       1.0 / (double)spp, d_frame_sum, d_rgb8);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+} // extern "C"

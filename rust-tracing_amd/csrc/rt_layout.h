@@ -1,0 +1,94 @@
+// Device-side scene layout (private to librt_amd; the ABI only sees rt_scene_desc).
+//
+// The reference walks a pointer tree recursively, always left child first (src/bvh.rs:97-108), list items in
+// order (src/hittable.rs:66-71).  Because that visiting order never depends on the ray, the whole object graph
+// can be laid out once in that order ("preorder") and walked without a stack: every record carries the index
+// of the record to continue with when its subtree is finished or its box is missed (`skip`); on a box hit the
+// walk simply continues with the next record.  Nested BVHs are spliced in place, a HittableList of quads or
+// spheres becomes one leaf record with a count, Translate/RotateY pairs become ENTER/EXIT records around their
+// subtree, and a ConstantMedium becomes ENTER/EXIT records around its boundary's subtree (walked twice).
+#pragma once
+#include "rt_amd.h"
+#include <cstdint>
+
+namespace rtd {
+
+enum NodeKind : uint32_t {
+    NK_INNER = 0,        // bounding box only
+    NK_SPHERES = 1,      // leaf: spheres [a, a+b)
+    NK_QUADS = 2,        // leaf: quads   [a, a+b)
+    NK_INST_ENTER = 3,   // a = instance index
+    NK_INST_EXIT = 4,    // a = instance index
+    NK_MEDIUM_ENTER = 5, // a = medium index
+    NK_MEDIUM_EXIT = 6,  // a = medium index, b = first record of the boundary subtree
+};
+constexpr uint32_t NODE_KIND_MASK = 0xffu;
+constexpr uint32_t NODE_NO_BBOX = 0x100u; // the reference performs no box test here (object inside a list /
+                                          // instance / medium): always enter
+
+// 64 bytes: four 16-byte loads per lane
+struct alignas(64) Node {
+    double lo[3];
+    double hi[3];
+    uint32_t skip;
+    uint32_t kind; // NodeKind | flags
+    uint32_t a;
+    uint32_t b;
+};
+static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
+
+// 64 bytes
+struct alignas(64) Sphere {
+    double center[3];
+    double radius;
+    double center_vec[3];
+    uint32_t material;
+    uint32_t is_moving;
+};
+static_assert(sizeof(Sphere) == 64, "Sphere must be 64 bytes");
+
+// 144 bytes; the plane (normal, d) comes first: most tests end after reading only that
+struct alignas(16) Quad {
+    double normal[3];
+    double d;
+    double q[3];
+    double w[3];
+    double u[3];
+    double v[3];
+    uint32_t material;
+    uint32_t _pad[3];
+};
+static_assert(sizeof(Quad) == 144, "Quad must be 144 bytes");
+
+// One frame change: optional Translate (applied to the ray first) then optional RotateY, i.e. the reference's
+// Translate::hit -> RotateY::hit nesting (src/hittable.rs:96-106,:159-188).  parent = enclosing instance or -1.
+struct alignas(64) Instance {
+    double offset[3];
+    double sin_theta, cos_theta;
+    int32_t parent;
+    uint32_t flags; // bit 0: has translate, bit 1: has rotate
+    uint32_t depth; // 0 for an instance in the world frame
+    uint32_t _pad[3];
+};
+static_assert(sizeof(Instance) == 64, "Instance must be 64 bytes");
+constexpr uint32_t INST_TRANSLATE = 1u, INST_ROTATE = 2u;
+
+struct alignas(16) Medium {
+    double neg_inv_density;
+    uint32_t phase_material;
+    uint32_t _pad;
+};
+
+struct alignas(16) ImageRef {
+    uint32_t width, height;
+    uint64_t offset; // byte offset of the first texel in the texel pool
+};
+
+// prim id stored with the closest hit: kind in the top 2 bits
+constexpr uint32_t PRIM_NONE = 0xffffffffu;
+constexpr uint32_t PRIM_SPHERE = 0u << 30, PRIM_QUAD = 1u << 30, PRIM_MEDIUM = 2u << 30;
+constexpr uint32_t PRIM_KIND_MASK = 3u << 30, PRIM_INDEX_MASK = ~PRIM_KIND_MASK;
+
+constexpr uint32_t MAX_INSTANCE_DEPTH = 4;
+
+} // namespace rtd

@@ -76,10 +76,22 @@ def lib():
 
 
 def default_threads() -> int:
+    """Threads for the CPU baseline: the cores this process may actually use (affinity mask, capped by the
+    cgroup CPU quota when there is one)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = os.cpu_count() or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("RT_ORACLE_THREADS")
+    if env:
+        n = int(env)
+    return max(1, min(n, 256))
 
 
 def render(host_scene, params, *, aabb_mode=ORC_AABB_REFERENCE, threads=None, camera=None, out=None,
