@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -56,17 +57,23 @@ struct KParams {
     const uint8_t *texels;
     const double *srgb_lut;
     double *out;
+    double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
     double *att_stack;              // [max_depth][n_threads][3]: attenuations of the current path
-    uint32_t *tile_counter;
+    uint32_t *job_counter;
     unsigned long long *counters;   // rt_counters as 10 u64, or null
     rt_camera cam;
     uint64_t seed_mixed;            // mix64(seed + gamma)
     uint32_t n_nodes;
     uint32_t n_threads;
-    int32_t sample_begin, sample_end, max_depth, accumulate;
+    int32_t sample_begin;           // first sample of this launch
+    uint32_t n_samples;             // samples per pixel in this launch
+    uint32_t n_jobs;                // n_local_tiles * n_samples * 64
+    int32_t max_depth, accumulate;
     int32_t shard_index, shard_count, out_layout;
     int32_t tiles_x;
     uint32_t n_local_tiles;
+    uint32_t th_prim, th_other, th_shade; // scheduler thresholds, in 64ths of the live lanes
+    uint32_t box_iters;             // box-test rounds per scheduler decision
 };
 
 struct Counts {
@@ -129,44 +136,40 @@ template <bool COUNT> RT_DEV V3 random_unit_vector(Rng &rng, Counts &cn) {
 }
 
 // ---- Perlin (src/perlin.rs:27-64,:81-100) ----------------------------------------------------------------
-__device__ __noinline__ double perlin_noise(const rt_perlin *pn, V3 p) {
-    const int32_t i = f64_as_i32(__builtin_floor(p.x));
-    const int32_t j = f64_as_i32(__builtin_floor(p.y));
-    const int32_t k = f64_as_i32(__builtin_floor(p.z));
-    const double u = p.x - (double)i;
-    const double v = p.y - (double)j;
-    const double w = p.z - (double)k;
-    const double uu = u * u * (3.0 - 2.0 * u);
-    const double vv = v * v * (3.0 - 2.0 * v);
-    const double ww = w * w * (3.0 - 2.0 * w);
-    double acc = 0.0;
-#pragma unroll
-    for (int di = 0; di < 2; ++di) {
-        const int32_t px = pn->perm_x[(uint32_t)(i + di) & 255u];
-        // `i as FP * uu + (1 - i) as FP * (1 - uu)` is exactly uu (i = 1) or 1 - uu (i = 0)
-        const double fi = di ? uu : 1.0 - uu;
-#pragma unroll
-        for (int dj = 0; dj < 2; ++dj) {
-            const int32_t py = pn->perm_y[(uint32_t)(j + dj) & 255u];
-            const double fj = dj ? vv : 1.0 - vv;
-#pragma unroll
-            for (int dk = 0; dk < 2; ++dk) {
-                const int32_t pz = pn->perm_z[(uint32_t)(k + dk) & 255u];
-                const double fk = dk ? ww : 1.0 - ww;
-                const V3 c = from(pn->ranvec[px ^ py ^ pz]);
-                const V3 weight_v = v3(u - (double)di, v - (double)dj, w - (double)dk);
-                acc += fi * fj * fk * dot(c, weight_v);
-            }
-        }
-    }
-    return acc;
-}
+// Rare and register-hungry: kept as rolled loops (one corner of the lattice cell per iteration) so that its
+// temporaries do not inflate the register allocation of the whole kernel.
 RT_DEV double perlin_turbulence(const rt_perlin *pn, V3 p, int depth) {
     double acc = 0.0;
-    double w = 1.0;
-    for (int d = 0; d < depth; ++d) {
-        acc += w * perlin_noise(pn, p);
-        w *= 0.5;
+    double wgt = 1.0;
+#pragma unroll 1
+    for (int dpt = 0; dpt < depth; ++dpt) {
+        // Perlin::noise (src/perlin.rs:27-50)
+        const int32_t i = f64_as_i32(__builtin_floor(p.x));
+        const int32_t j = f64_as_i32(__builtin_floor(p.y));
+        const int32_t k = f64_as_i32(__builtin_floor(p.z));
+        const double u = p.x - (double)i;
+        const double v = p.y - (double)j;
+        const double w = p.z - (double)k;
+        // trilinear_interpolation (src/perlin.rs:81-100)
+        const double uu = u * u * (3.0 - 2.0 * u);
+        const double vv = v * v * (3.0 - 2.0 * v);
+        const double ww = w * w * (3.0 - 2.0 * w);
+        double noise = 0.0;
+#pragma unroll 1
+        for (int corner = 0; corner < 8; ++corner) { // (di, dj, dk) in the reference's loop order: dk fastest
+            const int di = corner >> 2, dj = (corner >> 1) & 1, dk = corner & 1;
+            const int32_t idx = pn->perm_x[(uint32_t)(i + di) & 255u] ^ pn->perm_y[(uint32_t)(j + dj) & 255u] ^
+                                pn->perm_z[(uint32_t)(k + dk) & 255u];
+            const V3 c = from(pn->ranvec[idx]);
+            // `i as FP * uu + (1 - i) as FP * (1 - uu)` is exactly uu (i = 1) or 1 - uu (i = 0)
+            const double fi = di ? uu : 1.0 - uu;
+            const double fj = dj ? vv : 1.0 - vv;
+            const double fk = dk ? ww : 1.0 - ww;
+            const V3 weight_v = v3(u - (double)di, v - (double)dj, w - (double)dk);
+            noise += fi * fj * fk * dot(c, weight_v);
+        }
+        acc += wgt * noise;
+        wgt *= 0.5;
         p = p * 2.0;
     }
     return __builtin_fabs(acc);
@@ -202,68 +205,137 @@ template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, uint32_t tex, do
     return v3(s, s, s);
 }
 
-// ---- closest hit over the threaded layout ----------------------------------------------------------------
-struct Closest {
-    double t;
-    uint32_t prim; // PRIM_* | index, or PRIM_NONE
-    int32_t inst;  // frame the hit lives in
-};
+// ---- the render kernel: a wave-scheduled stage machine ----------------------------------------------------
+//
+// Work unit ("job") = one camera path = (pixel, sample).  Lanes are not tied to pixels: a lane that finishes a
+// path takes the next job of the wave's current job range, so no lane waits for a neighbour's longer path.
+// A path's colour goes to a sample buffer indexed by job; sum_samples_kernel then adds each pixel's samples in
+// order s = 0, 1, 2, ... — the reference's sequential `avg_color += new_color` (src/renderer.rs:35-40) — so
+// the result does not depend on which lane traced what, or when.
+//
+// Every lane is in one of a few stages (box test / sphere test / quad test / frame change or medium step /
+// shade+next ray).  Each scheduler round the wave counts its lanes per stage with ballots and runs ONE stage for
+// all the lanes in it: the rare stages are deferred until enough lanes have queued up for them, so that every
+// instruction stream the wave issues has most of its 64 lanes active.
+enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST_SHADE = 4, ST_DONE = 5 };
 
-template <bool COUNT>
-RT_DEV Closest traverse(const KParams &P, const V3 wo, const V3 wd, const double time, Rng &rng, Counts &cn) {
+constexpr uint32_t JOBS_PER_GRAB = 1024; // jobs a wave reserves at a time (16 sample-rows of one 8x8 tile)
+
+template <bool COUNT> __global__ __launch_bounds__(256) void path_kernel(const KParams P) {
     const double INF = __builtin_inf();
-    V3 o = wo, d = wd;
-    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); // AABB::hit divides per visit (src/aabb.rs:66): same quotient
-    double a = len2(d);                           // Sphere::hit's `a` (src/sphere.rs:66)
-    int32_t cur_inst = -1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree)
+    __shared__ double lds_world[6][256];
 
-    Closest best{INF, PRIM_NONE, -1};
-    // the interval box tests and primitive tests run against: ray_color's (0.001, closest so far)
-    // (src/renderer.rs:144) or, inside a ConstantMedium, the boundary query's own interval
-    double cur_tmin = 0.001, cur_tmax = INF;
-    // ConstantMedium state (src/constant_medium.rs:33-71): 0 = not in a medium, 1 = first boundary query, 2 = second
-    uint32_t mode = 0;
-    bool sub_hit = false;
-    double med_t1 = 0.0;
+    Counts cn{};
+    Rng rng;
+    rng.state = 0;
 
-    uint32_t node = 0;
-    while (node < P.n_nodes) {
-        const Node *np = &P.nodes[node];
-        const uint32_t kflags = np->kind;
-        const uint32_t skip = np->skip;
-        if (!(kflags & NODE_NO_BBOX)) {
-            if (COUNT) cn.node_visits++;
-            // slab test, interval narrowed axis by axis (see DESIGN.md "Box test" for why this cannot change a
-            // result relative to the reference's un-narrowed test)
-            double tmin = cur_tmin, tmax = cur_tmax;
-            bool miss = false;
-            {
-                double t0 = (np->lo[0] - o.x) * inv.x, t1 = (np->hi[0] - o.x) * inv.x;
-                if (inv.x < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-                tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
-                miss = tmax <= tmin;
-            }
-            if (!miss) {
-                double t0 = (np->lo[1] - o.y) * inv.y, t1 = (np->hi[1] - o.y) * inv.y;
-                if (inv.y < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-                tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
-                miss = tmax <= tmin;
-            }
-            if (!miss) {
-                double t0 = (np->lo[2] - o.z) * inv.z, t1 = (np->hi[2] - o.z) * inv.z;
-                if (inv.z < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-                tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
-                miss = tmax <= tmin;
-            }
-            if (miss) { node = skip; continue; }
+    // ---- per-lane path state ----
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0); // current-frame ray, 1/d
+    double a = 1.0, time = 0.0;                              // |d|^2 (Sphere::hit's `a`), ray time
+    uint32_t job = 0;
+    int32_t depth = 0;
+    uint32_t n_att = 0;
+    // ---- per-lane traversal state ----
+    double cur_tmin = 0.001, cur_tmax = INF; // interval tests run against (ray_color's, or a medium boundary query's)
+    double best_t = INF, med_t1 = 0.0;
+    uint32_t best_prim = PRIM_NONE;
+    int32_t best_inst = -1, cur_inst = -1;
+    uint32_t node = 0, prim_cur = 0, prim_end = 0;
+    uint32_t mode = 0; // ConstantMedium: 0 outside, 1 first boundary query, 2 second; bit 8: boundary was hit
+    uint32_t stage = ST_SHADE;
+    bool need_job = true;
+
+    double *att = P.att_stack + (size_t)gtid * 3u;
+    const size_t att_stride = (size_t)P.n_threads * 3u;
+
+    // wave-uniform: the job range this wave currently owns
+    uint32_t job_next = 0, job_end = 0;
+    bool jobs_left = true;
+
+    const uint32_t n_nodes = P.n_nodes;
+    const int32_t w = P.cam.image_width, h = P.cam.image_height;
+
+    for (;;) {
+        // ---------------- scheduler: which stage has enough lanes queued? ----------------
+        const uint32_t c_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
+        const uint32_t c_sph = (uint32_t)__popcll(__ballot(stage == ST_SPHERE));
+        const uint32_t c_quad = (uint32_t)__popcll(__ballot(stage == ST_QUAD));
+        const uint32_t c_oth = (uint32_t)__popcll(__ballot(stage == ST_OTHER));
+        const uint32_t c_shade = (uint32_t)__popcll(__ballot(stage == ST_SHADE));
+        const uint32_t live = c_box + c_sph + c_quad + c_oth + c_shade;
+        if (live == 0) break;
+        uint32_t run = ST_BOX, best_c = 0;
+        // a deferred stage becomes runnable once its queue holds th/64 of the live lanes ...
+        if (c_sph * 64u >= P.th_prim * live && c_sph > best_c) { run = ST_SPHERE; best_c = c_sph; }
+        if (c_quad * 64u >= P.th_prim * live && c_quad > best_c) { run = ST_QUAD; best_c = c_quad; }
+        if (c_oth * 64u >= P.th_other * live && c_oth > best_c) { run = ST_OTHER; best_c = c_oth; }
+        if (c_shade * 64u >= P.th_shade * live && c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
+        if (best_c == 0 && c_box == 0) { // ... or when nothing else can run
+            run = ST_SPHERE; best_c = c_sph;
+            if (c_quad > best_c) { run = ST_QUAD; best_c = c_quad; }
+            if (c_oth > best_c) { run = ST_OTHER; best_c = c_oth; }
+            if (c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
         }
-        const uint32_t kind = kflags & NODE_KIND_MASK;
-        const uint32_t na = np->a, nb = np->b;
-        if (kind == NK_INNER) {
-            node = node + 1;
-        } else if (kind == NK_SPHERES) {
-            for (uint32_t q = na; q < na + nb; ++q) { // Sphere::hit, src/sphere.rs:58-83
+
+        if (run == ST_BOX) {
+            // ---------------- box test + dispatch on the record kind ----------------
+#pragma unroll 1
+            for (uint32_t it = 0; it < P.box_iters; ++it) {
+                if (stage == ST_BOX) {
+                    const Node *np = &P.nodes[node];
+                    const uint32_t kflags = np->kind;
+                    const uint32_t skip = np->skip;
+                    bool miss = false;
+                    if (!(kflags & NODE_NO_BBOX)) {
+                        if (COUNT) cn.node_visits++;
+                        // slab test with the interval narrowed axis by axis (DESIGN.md "Box test": cannot change a
+                        // result relative to the reference's un-narrowed test, src/aabb.rs:64-84)
+                        double tmin = cur_tmin, tmax = cur_tmax;
+                        {
+                            double t0 = (np->lo[0] - o.x) * inv.x, t1 = (np->hi[0] - o.x) * inv.x;
+                            if (inv.x < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+                            tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
+                            miss = tmax <= tmin;
+                        }
+                        {
+                            double t0 = (np->lo[1] - o.y) * inv.y, t1 = (np->hi[1] - o.y) * inv.y;
+                            if (inv.y < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+                            tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
+                            miss = miss || tmax <= tmin;
+                        }
+                        {
+                            double t0 = (np->lo[2] - o.z) * inv.z, t1 = (np->hi[2] - o.z) * inv.z;
+                            if (inv.z < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+                            tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
+                            miss = miss || tmax <= tmin;
+                        }
+                    }
+                    if (miss) {
+                        node = skip;
+                    } else {
+                        const uint32_t kind = kflags & NODE_KIND_MASK;
+                        if (kind == NK_INNER) {
+                            node = node + 1;
+                        } else if (kind == NK_SPHERES || kind == NK_QUADS) {
+                            prim_cur = np->a;
+                            prim_end = prim_cur + np->b;
+                            node = skip; // where the walk continues after the leaf's primitives
+                            stage = kind == NK_SPHERES ? ST_SPHERE : ST_QUAD;
+                        } else {
+                            stage = ST_OTHER;
+                        }
+                    }
+                    if (stage == ST_BOX && node >= n_nodes) stage = ST_SHADE;
+                }
+            }
+        } else if (run == ST_SPHERE) {
+            // ---------------- Sphere::hit (src/sphere.rs:58-83), one sphere per round ----------------
+            if (stage == ST_SPHERE) {
                 if (COUNT) cn.sphere_tests++;
+                const uint32_t q = prim_cur;
                 const Sphere *s = &P.spheres[q];
                 V3 center = ld3(s->center);
                 if (s->is_moving) center = center + ld3(s->center_vec) * time;
@@ -271,283 +343,324 @@ RT_DEV Closest traverse(const KParams &P, const V3 wo, const V3 wd, const double
                 const double half_b = dot(oc, d);
                 const double c = len2(oc) - s->radius * s->radius;
                 const double discriminant = half_b * half_b - a * c;
-                if (discriminant < 0.0) continue;
-                const double sqrtd = __builtin_sqrt(discriminant);
-                double root = (-half_b - sqrtd) / a;
-                if (!(cur_tmin < root && root < cur_tmax)) {
-                    root = (-half_b + sqrtd) / a;
-                    if (!(cur_tmin < root && root < cur_tmax)) continue;
+                if (!(discriminant < 0.0)) {
+                    const double sqrtd = __builtin_sqrt(discriminant);
+                    double root = (-half_b - sqrtd) / a;
+                    bool ok = cur_tmin < root && root < cur_tmax;
+                    if (!ok) {
+                        root = (-half_b + sqrtd) / a;
+                        ok = cur_tmin < root && root < cur_tmax;
+                    }
+                    if (ok) {
+                        cur_tmax = root;
+                        if ((mode & 3u) == 0) { best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
+                        else mode |= 0x100u;
+                    }
                 }
-                cur_tmax = root;
-                if (mode == 0) { best.t = root; best.prim = PRIM_SPHERE | q; best.inst = cur_inst; }
-                else sub_hit = true;
+                prim_cur = q + 1;
+                if (prim_cur >= prim_end) stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
-            node = skip;
-        } else if (kind == NK_QUADS) {
-            for (uint32_t q = na; q < na + nb; ++q) { // Quad::hit, src/quad.rs:96-127
+        } else if (run == ST_QUAD) {
+            // ---------------- Quad::hit (src/quad.rs:96-127), one quad per round ----------------
+            if (stage == ST_QUAD) {
                 if (COUNT) cn.quad_tests++;
+                const uint32_t q = prim_cur;
                 const Quad *qd = &P.quads[q];
                 const V3 normal = ld3(qd->normal);
                 const double denom = dot(normal, d);
-                if (__builtin_fabs(denom) < 1e-8) continue;
-                const double t = (qd->d - dot(normal, o)) / denom;
-                if (!(cur_tmin <= t && t <= cur_tmax)) continue;
-                const V3 intersection = o + d * t;
-                const V3 php = intersection - ld3(qd->q);
-                const V3 w = ld3(qd->w);
-                const double alpha = dot(w, cross(php, ld3(qd->v)));
-                const double beta = dot(w, cross(ld3(qd->u), php));
-                if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
-                cur_tmax = t;
-                if (mode == 0) { best.t = t; best.prim = PRIM_QUAD | q; best.inst = cur_inst; }
-                else sub_hit = true;
-            }
-            node = skip;
-        } else if (kind == NK_INST_ENTER) {
-            if (COUNT) cn.instance_enters++;
-            apply_instance(P.insts[na], o, d);
-            inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-            a = len2(d);
-            cur_inst = (int32_t)na;
-            node = node + 1;
-        } else if (kind == NK_INST_EXIT) {
-            cur_inst = P.insts[na].parent;
-            o = wo; d = wd;
-            ray_to_frame(P.insts, cur_inst, o, d);
-            inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-            a = len2(d);
-            node = node + 1;
-        } else if (kind == NK_MEDIUM_ENTER) {
-            // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
-            if (COUNT) cn.medium_visits++;
-            mode = 1;
-            sub_hit = false;
-            cur_tmin = -INF;
-            cur_tmax = INF;
-            node = node + 1;
-        } else { // NK_MEDIUM_EXIT
-            bool again = false;
-            if (mode == 1) {
-                if (sub_hit) { // boundary.hit(r, (hit1.t + 0.0001, inf)) (src/constant_medium.rs:36-38)
-                    med_t1 = cur_tmax;
-                    mode = 2;
-                    sub_hit = false;
-                    cur_tmin = med_t1 + 0.0001;
-                    cur_tmax = INF;
-                    again = true;
-                }
-            } else if (sub_hit) { // src/constant_medium.rs:40-61
-                double h1 = __builtin_fmax(med_t1, 0.001);
-                const double h2 = __builtin_fmin(cur_tmax, best.t);
-                if (h1 < h2) {
-                    h1 = __builtin_fmax(h1, 0.0);
-                    const double ray_length = __builtin_sqrt(len2(d));
-                    const double distance_inside_boundary = (h2 - h1) * ray_length;
-                    if (COUNT) cn.rng_draws++;
-                    const double hit_distance = P.media[na].neg_inv_density * rt_log(rng.random());
-                    if (hit_distance <= distance_inside_boundary) {
-                        best.t = h1 + hit_distance / ray_length;
-                        best.prim = PRIM_MEDIUM | na;
-                        best.inst = cur_inst;
+                if (!(__builtin_fabs(denom) < 1e-8)) {
+                    const double t = (qd->d - dot(normal, o)) / denom;
+                    if (cur_tmin <= t && t <= cur_tmax) {
+                        const V3 intersection = o + d * t;
+                        const V3 php = intersection - ld3(qd->q);
+                        const V3 qw = ld3(qd->w);
+                        const double alpha = dot(qw, cross(php, ld3(qd->v)));
+                        const double beta = dot(qw, cross(ld3(qd->u), php));
+                        if (!(alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0)) {
+                            cur_tmax = t;
+                            if ((mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
+                            else mode |= 0x100u;
+                        }
                     }
                 }
+                prim_cur = q + 1;
+                if (prim_cur >= prim_end) stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
-            if (again) {
-                node = nb;
-            } else {
+        } else if (run == ST_OTHER) {
+            // ---------------- frame changes and ConstantMedium steps ----------------
+            if (stage == ST_OTHER) {
+                const Node *np = &P.nodes[node];
+                const uint32_t kind = np->kind & NODE_KIND_MASK;
+                const uint32_t na = np->a;
+                if (kind == NK_INST_ENTER) {
+                    if (COUNT) cn.instance_enters++;
+                    if (cur_inst < 0) { // leaving the world frame: park the world ray
+                        lds_world[0][threadIdx.x] = o.x; lds_world[1][threadIdx.x] = o.y; lds_world[2][threadIdx.x] = o.z;
+                        lds_world[3][threadIdx.x] = d.x; lds_world[4][threadIdx.x] = d.y; lds_world[5][threadIdx.x] = d.z;
+                    }
+                    apply_instance(P.insts[na], o, d);
+                    cur_inst = (int32_t)na;
+                    node = node + 1;
+                } else if (kind == NK_INST_EXIT) {
+                    cur_inst = P.insts[na].parent;
+                    o = v3(lds_world[0][threadIdx.x], lds_world[1][threadIdx.x], lds_world[2][threadIdx.x]);
+                    d = v3(lds_world[3][threadIdx.x], lds_world[4][threadIdx.x], lds_world[5][threadIdx.x]);
+                    ray_to_frame(P.insts, cur_inst, o, d);
+                    node = node + 1;
+                } else if (kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
+                    if (COUNT) cn.medium_visits++;
+                    mode = 1;
+                    cur_tmin = -INF;
+                    cur_tmax = INF;
+                    node = node + 1;
+                } else { // NK_MEDIUM_EXIT
+                    bool again = false;
+                    const bool sub_hit = (mode & 0x100u) != 0;
+                    if ((mode & 3u) == 1) {
+                        if (sub_hit) { // boundary.hit(r, (hit1.t + 0.0001, inf)) (src/constant_medium.rs:36-38)
+                            med_t1 = cur_tmax;
+                            mode = 2;
+                            cur_tmin = med_t1 + 0.0001;
+                            cur_tmax = INF;
+                            again = true;
+                        }
+                    } else if (sub_hit) { // src/constant_medium.rs:40-61
+                        double h1 = __builtin_fmax(med_t1, 0.001);
+                        const double h2 = __builtin_fmin(cur_tmax, best_t);
+                        if (h1 < h2) {
+                            h1 = __builtin_fmax(h1, 0.0);
+                            const double ray_length = __builtin_sqrt(len2(d));
+                            const double distance_inside_boundary = (h2 - h1) * ray_length;
+                            if (COUNT) cn.rng_draws++;
+                            const double hit_distance = P.media[na].neg_inv_density * rt_log(rng.random());
+                            if (hit_distance <= distance_inside_boundary) {
+                                best_t = h1 + hit_distance / ray_length;
+                                best_prim = PRIM_MEDIUM | na;
+                                best_inst = cur_inst;
+                            }
+                        }
+                    }
+                    if (again) {
+                        node = np->b;
+                    } else {
+                        mode = 0;
+                        cur_tmin = 0.001;
+                        cur_tmax = best_t;
+                        node = node + 1;
+                    }
+                }
+                if (kind == NK_INST_ENTER || kind == NK_INST_EXIT) {
+                    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                    a = len2(d);
+                }
+                stage = node >= n_nodes ? ST_SHADE : ST_BOX;
+            }
+        } else {
+            // ---------------- shade the finished closest-hit query; start the next ray or the next path ----------------
+            const bool shading = stage == ST_SHADE;
+            V3 result = v3(0.0, 0.0, 0.0);
+            bool path_done = false;
+            if (shading && !need_job) {
+                // ray_color (src/renderer.rs:139-155), one level of the recursion per visit.  In this codebase a material
+                // that scatters emits nothing and the one that emits never scatters, so the recursion unrolls to
+                //     A_1 * (A_2 * ( ... (A_n * terminal)))
+                // evaluated innermost first; attenuations are parked in att_stack and multiplied back at the end.
+                if (best_prim == PRIM_NONE) {
+                    result = from(P.cam.background);
+                    path_done = true;
+                } else {
+                    // rebuild the HitRecord in its own frame, then carry it to the world
+                    V3 lo = o, ld = d; // all frames are closed at this point: (o, d) is the world ray
+                    ray_to_frame(P.insts, best_inst, lo, ld);
+                    V3 p = lo + ld * best_t; // Ray::at (src/ray.rs:30-32)
+                    V3 outward_normal;
+                    uint32_t mat;
+                    double u = 0.0, v = 0.0;
+                    const uint32_t pk = best_prim & PRIM_KIND_MASK, pi = best_prim & PRIM_INDEX_MASK;
+                    bool uv_from_sphere = false;
+                    if (pk == PRIM_SPHERE) { // src/sphere.rs:85-88
+                        const Sphere *s = &P.spheres[pi];
+                        V3 center = ld3(s->center);
+                        if (s->is_moving) center = center + ld3(s->center_vec) * time;
+                        outward_normal = div(p - center, s->radius);
+                        mat = s->material;
+                        uv_from_sphere = true;
+                    } else if (pk == PRIM_QUAD) { // src/quad.rs:118-132
+                        const Quad *qd = &P.quads[pi];
+                        outward_normal = ld3(qd->normal);
+                        mat = qd->material;
+                        if (P.mats[mat].needs_uv) {
+                            const V3 php = p - ld3(qd->q);
+                            const V3 qw = ld3(qd->w);
+                            u = dot(qw, cross(php, ld3(qd->v)));
+                            v = dot(qw, cross(ld3(qd->u), php));
+                        }
+                    } else { // ConstantMedium: normal := r.direction (src/constant_medium.rs:52-58)
+                        outward_normal = ld;
+                        mat = P.media[pi].phase_material;
+                    }
+                    const DMaterial *m = &P.mats[mat];
+                    if (uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
+                        const double PI = 3.14159265358979323846264338327950288;
+                        const double theta = rt_acos(-outward_normal.y);
+                        const double phi = rt_atan2(-outward_normal.z, outward_normal.x) + PI;
+                        u = phi / (2.0 * PI);
+                        v = theta / PI;
+                    }
+                    // HitRecord::new (src/hittable.rs:22-37)
+                    const bool front_face = dot(ld, outward_normal) < 0.0;
+                    V3 normal = front_face ? outward_normal : -outward_normal;
+                    hit_to_world(P.insts, best_inst, p, normal);
+
+                    const uint32_t mk = m->kind;
+                    // Every material that reads a texture reads exactly one, after its random draws (textures draw
+                    // nothing): evaluate it at one place.  Likewise the unit-sphere rejection sample
+                    // (src/vec3.rs:54-61) is the first draw of Lambertian, Metal and Isotropic alike.
+                    V3 tex = v3(1.0, 1.0, 1.0);
+                    V3 rs = v3(0.0, 0.0, 0.0);
+                    if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
+                    if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) tex = texture_value<COUNT>(P, m->texture, u, v, p, cn);
+                    V3 attenuation = tex;
+                    bool unit_attenuation = false;
+                    V3 new_dir = normal;
+                    if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
+                        result = tex;
+                        path_done = true;
+                    } else if (mk == RT_MATERIAL_LAMBERTIAN) { // src/material.rs:26-42
+                        const V3 scatter_direction = normal + normalize(rs);
+                        new_dir = near_zero(scatter_direction) ? normal : scatter_direction;
+                    } else if (mk == RT_MATERIAL_METAL) { // src/material.rs:53-64
+                        const V3 refl = reflect(normalize(d), normal);
+                        const V3 reflected = refl + rs * m->fuzz;
+                        if (!(dot(reflected, normal) > 0.0)) path_done = true; // absorbed: emission (zero) only
+                        new_dir = reflected;
+                        attenuation = ld3(m->albedo);
+                    } else if (mk == RT_MATERIAL_DIELECTRIC) { // src/material.rs:80-104
+                        const double refraction_ratio = front_face ? 1.0 / m->ir : m->ir;
+                        const V3 unit_direction = normalize(d);
+                        const double cos_theta = __builtin_fmin(dot(-unit_direction, normal), 1.0);
+                        const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+                        bool do_reflect = refraction_ratio * sin_theta > 1.0;
+                        if (!do_reflect) { // `||` short-circuit: draw only when refraction is possible
+                            double r0 = (1.0 - refraction_ratio) / (1.0 + refraction_ratio);
+                            r0 = r0 * r0;
+                            const double reflectance = r0 + (1.0 - r0) * rt_pow5(1.0 - cos_theta);
+                            if (COUNT) cn.rng_draws++;
+                            do_reflect = reflectance > rng.random();
+                        }
+                        new_dir = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
+                        unit_attenuation = true; // Color::ONE: multiplying by it is the identity, nothing to park
+                    } else { // RT_MATERIAL_ISOTROPIC, src/material.rs:132-138
+                        new_dir = normalize(rs);
+                    }
+                    if (!path_done) {
+                        if (!unit_attenuation) {
+                            double *slot = att + (size_t)n_att * att_stride;
+                            slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
+                            n_att++;
+                        }
+                        depth--;
+                        if (depth <= 0) { // the next ray_color call returns Color::ZERO at once
+                            path_done = true;
+                        } else {
+                            o = p;
+                            d = new_dir;
+                        }
+                    }
+                }
+                if (path_done) {
+                    // attenuation * ray_color(...), innermost first.  A zero terminal stays zero (attenuations are finite).
+                    if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
+                        while (n_att > 0) {
+                            n_att--;
+                            const double *slot = att + (size_t)n_att * att_stride;
+                            result = v3(slot[0], slot[1], slot[2]) * result;
+                        }
+                    }
+                    double *dst = P.samples + (size_t)job * 3u;
+                    dst[0] = result.x; dst[1] = result.y; dst[2] = result.z;
+                    if (COUNT) cn.samples++;
+                    need_job = true;
+                }
+            }
+            // ---- hand out jobs to the lanes that need one (wave-level: ballot + prefix count) ----
+            const uint64_t want = __ballot(shading && need_job);
+            const uint32_t n_want = (uint32_t)__popcll(want);
+            if (n_want) {
+                if (jobs_left && job_end - job_next < n_want) {
+                    // not enough left in the wave's range: hand those out first (below), then reserve a new range
+                    // next round; simplest is to reserve now when the range is empty
+                    if (job_next == job_end) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(P.job_counter, JOBS_PER_GRAB);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= P.n_jobs) { jobs_left = false; }
+                        else { job_next = base; job_end = base + JOBS_PER_GRAB < P.n_jobs ? base + JOBS_PER_GRAB : P.n_jobs; }
+                    }
+                }
+                const uint32_t avail = job_end - job_next;
+                const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                if (shading && need_job) {
+                    if (rank < avail) {
+                        job = job_next + rank;
+                        // job -> (local tile, sample, pixel): ((lt * S + s_rel) * 64 + p)
+                        const uint32_t p64 = job & 63u;
+                        const uint32_t row = job >> 6;
+                        const uint32_t lt = row / P.n_samples, s_rel = row - lt * P.n_samples;
+                        const uint32_t k = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
+                        const int32_t i = (int32_t)(k % (uint32_t)P.tiles_x) * RT_TILE_W + (int32_t)(p64 & 7u);
+                        const int32_t j = (int32_t)(k / (uint32_t)P.tiles_x) * RT_TILE_H + (int32_t)(p64 >> 3);
+                        if (i < w && j < h) {
+                            const uint32_t pixel = (uint32_t)j * (uint32_t)w + (uint32_t)i; // screen_pos (src/renderer.rs:32-33)
+                            rng.start(P.seed_mixed, pixel, (uint32_t)P.sample_begin + s_rel);
+                            // Camera::get_ray (src/camera.rs:112-137)
+                            const rt_camera &cam = P.cam;
+                            const V3 du = from(cam.pixel_delta_u), dv = from(cam.pixel_delta_v);
+                            const V3 pixel_center = from(cam.pixel00_loc) + du * (double)i + dv * (double)j;
+                            const double px = -0.5 + rng.random();
+                            const double py = -0.5 + rng.random();
+                            if (COUNT) cn.rng_draws += 2;
+                            const V3 pixel_sample = pixel_center + (du * px + dv * py);
+                            V3 ro;
+                            if (cam.defocus_angle <= 0.0) {
+                                ro = from(cam.center);
+                            } else { // random_in_unit_disk (src/vec3.rs:77-88)
+                                double dx, dy;
+                                for (;;) {
+                                    dx = rng.range(-1.0, 1.0);
+                                    dy = rng.range(-1.0, 1.0);
+                                    if (COUNT) cn.rng_draws += 2;
+                                    if (dx * dx + dy * dy + 0.0 * 0.0 < 1.0) break;
+                                }
+                                ro = from(cam.center) + from(cam.defocus_disk_u) * dx + from(cam.defocus_disk_v) * dy;
+                            }
+                            o = ro;
+                            d = pixel_sample - ro;
+                            time = rng.random();
+                            if (COUNT) cn.rng_draws += 1;
+                            depth = P.max_depth;
+                            n_att = 0;
+                            need_job = false;
+                        }
+                        // a job of a padding pixel (edge tile) traces nothing; the lane asks again next round
+                    } else if (!jobs_left || avail == 0) {
+                        if (!jobs_left) stage = ST_DONE;
+                    }
+                }
+                job_next += n_want < avail ? n_want : avail;
+            }
+            // ---- start the closest-hit query of the next ray ----
+            if (shading && stage == ST_SHADE && !need_job) {
+                if (COUNT) cn.rays++;
+                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); // AABB::hit divides per visit (src/aabb.rs:66): same quotient
+                a = len2(d);
+                cur_tmin = 0.001; cur_tmax = INF; // (0.001, inf) (src/renderer.rs:144)
+                best_t = INF; best_prim = PRIM_NONE; best_inst = -1; cur_inst = -1;
                 mode = 0;
-                cur_tmin = 0.001;
-                cur_tmax = best.t;
-                node = node + 1;
+                node = 0;
+                stage = ST_BOX;
             }
         }
-    }
-    return best;
-}
-
-// ---- one camera path: Camera::get_ray + ray_color ---------------------------------------------------------
-template <bool COUNT>
-RT_DEV V3 trace_sample(const KParams &P, const int32_t i, const int32_t j, Rng &rng, const uint32_t gtid, Counts &cn) {
-    const rt_camera &cam = P.cam;
-    // Camera::get_ray (src/camera.rs:112-137)
-    const V3 du = from(cam.pixel_delta_u), dv = from(cam.pixel_delta_v);
-    const V3 pixel_center = from(cam.pixel00_loc) + du * (double)i + dv * (double)j;
-    const double px = -0.5 + rng.random();
-    const double py = -0.5 + rng.random();
-    if (COUNT) cn.rng_draws += 2;
-    const V3 pixel_sample = pixel_center + (du * px + dv * py);
-    V3 ro;
-    if (cam.defocus_angle <= 0.0) {
-        ro = from(cam.center);
-    } else { // random_in_unit_disk (src/vec3.rs:77-88)
-        double dx, dy;
-        for (;;) {
-            dx = rng.range(-1.0, 1.0);
-            dy = rng.range(-1.0, 1.0);
-            if (COUNT) cn.rng_draws += 2;
-            if (dx * dx + dy * dy + 0.0 * 0.0 < 1.0) break;
-        }
-        ro = from(cam.center) + from(cam.defocus_disk_u) * dx + from(cam.defocus_disk_v) * dy;
-    }
-    V3 rd = pixel_sample - ro;
-    const double time = rng.random();
-    if (COUNT) cn.rng_draws += 1;
-
-    // ray_color (src/renderer.rs:139-155), iteratively.  In this codebase a material that scatters emits
-    // nothing and the one that emits never scatters, so the recursion unrolls to
-    //     A_1 * (A_2 * ( ... (A_n * terminal)))
-    // evaluated innermost first; the attenuations are parked in att_stack and multiplied back in that order.
-    int32_t depth = P.max_depth;
-    uint32_t n_att = 0;
-    V3 result = v3(0.0, 0.0, 0.0);
-    double *att = P.att_stack + (size_t)gtid * 3u;
-    const size_t att_stride = (size_t)P.n_threads * 3u;
-
-    for (;;) {
-        if (depth <= 0) break; // Color::ZERO
-        if (COUNT) cn.rays++;
-        const Closest hit = traverse<COUNT>(P, ro, rd, time, rng, cn);
-        if (hit.prim == PRIM_NONE) { result = from(cam.background); break; }
-
-        // rebuild the HitRecord of the closest hit in its own frame, then carry it to the world
-        V3 lo = ro, ld = rd;
-        ray_to_frame(P.insts, hit.inst, lo, ld);
-        V3 p = lo + ld * hit.t; // Ray::at (src/ray.rs:30-32)
-        V3 outward_normal;
-        uint32_t mat;
-        double u = 0.0, v = 0.0;
-        const uint32_t pk = hit.prim & PRIM_KIND_MASK, pi = hit.prim & PRIM_INDEX_MASK;
-        bool uv_from_sphere = false;
-        if (pk == PRIM_SPHERE) { // src/sphere.rs:85-88
-            const Sphere *s = &P.spheres[pi];
-            V3 center = ld3(s->center);
-            if (s->is_moving) center = center + ld3(s->center_vec) * time;
-            outward_normal = div(p - center, s->radius);
-            mat = s->material;
-            uv_from_sphere = true;
-        } else if (pk == PRIM_QUAD) { // src/quad.rs:118-132
-            const Quad *qd = &P.quads[pi];
-            outward_normal = ld3(qd->normal);
-            mat = qd->material;
-            if (P.mats[mat].needs_uv) {
-                const V3 php = p - ld3(qd->q);
-                const V3 w = ld3(qd->w);
-                u = dot(w, cross(php, ld3(qd->v)));
-                v = dot(w, cross(ld3(qd->u), php));
-            }
-        } else { // ConstantMedium: normal := r.direction (src/constant_medium.rs:52-58)
-            outward_normal = ld;
-            mat = P.media[pi].phase_material;
-        }
-        const DMaterial *m = &P.mats[mat];
-        if (uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
-            const double PI = 3.14159265358979323846264338327950288;
-            const double theta = rt_acos(-outward_normal.y);
-            const double phi = rt_atan2(-outward_normal.z, outward_normal.x) + PI;
-            u = phi / (2.0 * PI);
-            v = theta / PI;
-        }
-        // HitRecord::new (src/hittable.rs:22-37)
-        const bool front_face = dot(ld, outward_normal) < 0.0;
-        V3 normal = front_face ? outward_normal : -outward_normal;
-        hit_to_world(P.insts, hit.inst, p, normal);
-
-        const uint32_t mk = m->kind;
-        // Every material that reads a texture reads exactly one, after its random draws (which textures never
-        // make): evaluate it at one place.  Likewise the unit-sphere rejection sample (src/vec3.rs:54-61) is
-        // the first draw of Lambertian, Metal and Isotropic alike.
-        V3 tex = v3(1.0, 1.0, 1.0);
-        V3 rs = v3(0.0, 0.0, 0.0);
-        if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
-        if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) tex = texture_value<COUNT>(P, m->texture, u, v, p, cn);
-        if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
-            result = tex;
-            break;
-        }
-        V3 attenuation = tex;
-        bool unit_attenuation = false;
-        V3 new_dir;
-        if (mk == RT_MATERIAL_LAMBERTIAN) { // src/material.rs:26-42
-            const V3 scatter_direction = normal + normalize(rs);
-            new_dir = near_zero(scatter_direction) ? normal : scatter_direction;
-        } else if (mk == RT_MATERIAL_METAL) { // src/material.rs:53-64
-            const V3 refl = reflect(normalize(rd), normal);
-            const V3 reflected = refl + rs * m->fuzz;
-            if (!(dot(reflected, normal) > 0.0)) break; // absorbed: emission (zero) only
-            new_dir = reflected;
-            attenuation = ld3(m->albedo);
-        } else if (mk == RT_MATERIAL_DIELECTRIC) { // src/material.rs:80-104
-            const double refraction_ratio = front_face ? 1.0 / m->ir : m->ir;
-            const V3 unit_direction = normalize(rd);
-            const double cos_theta = __builtin_fmin(dot(-unit_direction, normal), 1.0);
-            const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-            bool do_reflect = refraction_ratio * sin_theta > 1.0;
-            if (!do_reflect) { // `||` short-circuit: draw only when refraction is possible
-                double r0 = (1.0 - refraction_ratio) / (1.0 + refraction_ratio);
-                r0 = r0 * r0;
-                const double reflectance = r0 + (1.0 - r0) * rt_pow5(1.0 - cos_theta);
-                if (COUNT) cn.rng_draws++;
-                do_reflect = reflectance > rng.random();
-            }
-            new_dir = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
-            unit_attenuation = true; // Color::ONE: multiplying by it is the identity, nothing to park
-        } else { // RT_MATERIAL_ISOTROPIC, src/material.rs:132-138
-            new_dir = normalize(rs);
-        }
-        if (!unit_attenuation) {
-            double *slot = att + (size_t)n_att * att_stride;
-            slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
-            n_att++;
-        }
-        ro = p;
-        rd = new_dir;
-        depth--;
-    }
-    // attenuation * ray_color(...), innermost first.  A zero terminal stays zero (attenuations are finite).
-    if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
-        while (n_att > 0) {
-            n_att--;
-            const double *slot = att + (size_t)n_att * att_stride;
-            result = v3(slot[0], slot[1], slot[2]) * result;
-        }
-    }
-    return result;
-}
-
-template <bool COUNT> __global__ __launch_bounds__(256) void render_kernel(const KParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t w = P.cam.image_width, h = P.cam.image_height;
-    Counts cn{};
-    Rng rng;
-
-    for (;;) {
-        // the wave takes the next tile of this shard
-        uint32_t lt = 0;
-        if (lane == 0) lt = atomicAdd(P.tile_counter, 1u);
-        lt = (uint32_t)__builtin_amdgcn_readfirstlane((int)lt);
-        if (lt >= P.n_local_tiles) break;
-        const uint32_t k = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
-        const int32_t i = (int32_t)(k % (uint32_t)P.tiles_x) * RT_TILE_W + (int32_t)(lane & 7u);
-        const int32_t j = (int32_t)(k / (uint32_t)P.tiles_x) * RT_TILE_H + (int32_t)(lane >> 3);
-        const bool valid = i < w && j < h;
-        double *dst = nullptr;
-        if (P.out_layout == RT_OUT_TILES) dst = P.out + ((size_t)lt * 64u + lane) * 3u;
-        else if (valid) dst = P.out + ((size_t)j * (size_t)w + (size_t)i) * 3u;
-        if (!valid) {
-            if (dst) { dst[0] = 0.0; dst[1] = 0.0; dst[2] = 0.0; }
-            continue;
-        }
-        V3 acc = v3(0.0, 0.0, 0.0);
-        if (P.accumulate) acc = v3(dst[0], dst[1], dst[2]);
-        const uint32_t pixel = (uint32_t)j * (uint32_t)w + (uint32_t)i; // screen_pos (src/renderer.rs:32-33)
-        for (int32_t s = P.sample_begin; s < P.sample_end; ++s) {      // src/renderer.rs:35-40
-            rng.start(P.seed_mixed, pixel, (uint32_t)s);
-            const V3 c = trace_sample<COUNT>(P, i, j, rng, gtid, cn);
-            acc = acc + c;
-            if (COUNT) cn.samples++;
-        }
-        dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
     }
 
     if (COUNT && P.counters) {
@@ -561,6 +674,34 @@ template <bool COUNT> __global__ __launch_bounds__(256) void render_kernel(const
             if (lane == 0 && v) atomicAdd(&P.counters[q], v);
         }
     }
+}
+
+// Per-pixel sum of the sample buffer in sample order (src/renderer.rs:35-40: `avg_color += new_color`).
+// One thread per (local tile, pixel of the tile); consecutive threads read consecutive 24-byte samples.
+__global__ void sum_samples_kernel(const KParams P) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lt = idx >> 6, p64 = idx & 63u;
+    if (lt >= P.n_local_tiles) return;
+    const int32_t w = P.cam.image_width, h = P.cam.image_height;
+    const uint32_t k = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
+    const int32_t i = (int32_t)(k % (uint32_t)P.tiles_x) * RT_TILE_W + (int32_t)(p64 & 7u);
+    const int32_t j = (int32_t)(k / (uint32_t)P.tiles_x) * RT_TILE_H + (int32_t)(p64 >> 3);
+    const bool valid = i < w && j < h;
+    double *dst = nullptr;
+    if (P.out_layout == RT_OUT_TILES) dst = P.out + ((size_t)lt * 64u + p64) * 3u;
+    else if (valid) dst = P.out + ((size_t)j * (size_t)w + (size_t)i) * 3u;
+    if (!valid) {
+        if (dst) { dst[0] = 0.0; dst[1] = 0.0; dst[2] = 0.0; }
+        return;
+    }
+    V3 acc = v3(0.0, 0.0, 0.0);
+    if (P.accumulate) acc = v3(dst[0], dst[1], dst[2]);
+    const double *src = P.samples + ((size_t)lt * P.n_samples * 64u + p64) * 3u;
+    for (uint32_t s = 0; s < P.n_samples; ++s) {
+        acc = acc + v3(src[0], src[1], src[2]);
+        src += 64u * 3u;
+    }
+    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
 }
 
 // frame-end reassembly: [shard][local tile][64][3] -> row-major frame
@@ -648,9 +789,25 @@ int fail(int status, const std::string &msg) {
 struct Workspace {
     double *att_stack = nullptr;
     size_t att_bytes = 0;
-    uint32_t *tile_counter = nullptr;
+    double *samples = nullptr; // sample buffer of one launch
+    size_t sample_bytes = 0;
+    uint32_t *job_counter = nullptr;
     unsigned long long *counters = nullptr;
 };
+
+// Scheduler knobs (64ths of the live lanes a deferred stage must have queued; box rounds per decision).
+// Defaults were picked on MI355X with bench.py (DESIGN.md "Scheduler"); the RT_* variables are for tuning runs.
+struct Tuning {
+    uint32_t th_prim = 16, th_other = 16, th_shade = 24, box_iters = 2;
+    size_t sample_buffer_bytes = (size_t)16 << 30;
+    Tuning() {
+        auto env = [](const char *name, uint32_t &v) { if (const char *e = getenv(name)) v = (uint32_t)strtoul(e, nullptr, 10); };
+        env("RT_TH_PRIM", th_prim); env("RT_TH_OTHER", th_other); env("RT_TH_SHADE", th_shade); env("RT_BOX_ITERS", box_iters);
+        if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
+        if (box_iters < 1) box_iters = 1;
+    }
+};
+const Tuning &tuning() { static const Tuning t; return t; }
 
 template <class T> struct DeviceArray {
     T *ptr = nullptr;
@@ -706,7 +863,8 @@ void free_scene(rt_scene *s) {
     (void)hipSetDevice(s->device);
     for (auto &kv : s->workspaces) {
         (void)hipFree(kv.second.att_stack);
-        (void)hipFree(kv.second.tile_counter);
+        (void)hipFree(kv.second.samples);
+        (void)hipFree(kv.second.job_counter);
         (void)hipFree(kv.second.counters);
     }
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
@@ -743,16 +901,27 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     HIP_TRY(hipSetDevice(scene->device));
     const bool counted = out_counters != nullptr;
     const int64_t n_local = tiles_local(camera->image_width, camera->image_height, p.shard_index, p.shard_count);
-    if (n_local <= 0) {
+    const int64_t n_samples_total = (int64_t)p.sample_end - p.sample_begin;
+    if (n_local <= 0 || n_samples_total <= 0) {
         if (out_counters) *out_counters = rt_counters{};
         return RT_OK;
     }
+    const Tuning &tn = tuning();
+
+    // samples per launch: bounded by the sample buffer and by the 32-bit job index
+    const int64_t bytes_per_sample_row = n_local * 64 * 3 * (int64_t)sizeof(double);
+    int64_t chunk = (int64_t)(tn.sample_buffer_bytes / (size_t)bytes_per_sample_row);
+    const int64_t max_by_index = ((int64_t)1 << 31) / (n_local * 64);
+    if (chunk > max_by_index) chunk = max_by_index;
+    if (chunk > n_samples_total) chunk = n_samples_total;
+    if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
 
     const int threads = 256;
     const int bpc = scene->blocks_per_cu[counted ? 1 : 0];
-    int64_t grid = (n_local + 3) / 4; // 4 waves per block, one tile per wave at a time
-    const int64_t resident = (int64_t)scene->n_cus * bpc;
-    if (grid > resident) grid = resident;
+    // persistent grid: every resident wave pulls jobs until none are left
+    int64_t grid = (int64_t)scene->n_cus * bpc;
+    const int64_t max_useful = (n_local * 64 * chunk + JOBS_PER_GRAB * 4 - 1) / (JOBS_PER_GRAB * 4);
+    if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
     const uint32_t n_threads = (uint32_t)(grid * threads);
 
@@ -760,22 +929,25 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     {
         std::lock_guard<std::mutex> lock(scene->mu);
         Workspace &w = scene->workspaces[stream];
-        const size_t need = (size_t)p.max_depth * n_threads * 3u * sizeof(double);
-        if (w.att_bytes < need) {
-            if (w.att_stack) {
-                HIP_TRY(hipStreamSynchronize(stream));
-                HIP_TRY(hipFree(w.att_stack));
-                w.att_stack = nullptr;
-                w.att_bytes = 0;
-            }
-            HIP_TRY(hipMalloc((void **)&w.att_stack, need));
-            w.att_bytes = need;
+        const size_t need_att = (size_t)p.max_depth * n_threads * 3u * sizeof(double);
+        const size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+        if (w.att_bytes < need_att || w.sample_bytes < need_samples) HIP_TRY(hipStreamSynchronize(stream));
+        if (w.att_bytes < need_att) {
+            if (w.att_stack) HIP_TRY(hipFree(w.att_stack));
+            w.att_stack = nullptr; w.att_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&w.att_stack, need_att));
+            w.att_bytes = need_att;
         }
-        if (!w.tile_counter) HIP_TRY(hipMalloc((void **)&w.tile_counter, sizeof(uint32_t)));
+        if (w.sample_bytes < need_samples) {
+            if (w.samples) HIP_TRY(hipFree(w.samples));
+            w.samples = nullptr; w.sample_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&w.samples, need_samples));
+            w.sample_bytes = need_samples;
+        }
+        if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 10 * sizeof(unsigned long long)));
         ws = w;
     }
-    HIP_TRY(hipMemsetAsync(ws.tile_counter, 0, sizeof(uint32_t), stream));
     if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 10 * sizeof(unsigned long long), stream));
 
     KParams K{};
@@ -783,21 +955,34 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
     K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
     K.out = d_out;
+    K.samples = ws.samples;
     K.att_stack = ws.att_stack;
-    K.tile_counter = ws.tile_counter;
+    K.job_counter = ws.job_counter;
     K.counters = counted ? ws.counters : nullptr;
     K.cam = *camera;
     K.seed_mixed = rtk_host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
     K.n_nodes = scene->n_nodes;
     K.n_threads = n_threads;
-    K.sample_begin = p.sample_begin; K.sample_end = p.sample_end; K.max_depth = p.max_depth; K.accumulate = p.accumulate;
+    K.max_depth = p.max_depth;
     K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
     K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
     K.n_local_tiles = (uint32_t)n_local;
+    K.th_prim = tn.th_prim; K.th_other = tn.th_other; K.th_shade = tn.th_shade; K.box_iters = tn.box_iters;
 
-    if (counted) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
-    HIP_TRY(hipGetLastError());
+    const unsigned sum_grid = (unsigned)((n_local * 64 + threads - 1) / threads);
+    for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk) {
+        const int64_t ns = (p.sample_end - sb) < chunk ? (p.sample_end - sb) : chunk;
+        K.sample_begin = (int32_t)sb;
+        K.n_samples = (uint32_t)ns;
+        K.n_jobs = (uint32_t)(n_local * 64 * ns);
+        K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
+        HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
+        if (counted) hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
+        else hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(threads), 0, stream, K);
+        HIP_TRY(hipGetLastError());
+    }
 
     if (counted) {
         unsigned long long host[10];
@@ -855,8 +1040,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "hipGetDeviceProperties failed"); }
     s->n_cus = prop.multiProcessorCount;
     int b0 = 0, b1 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, render_kernel<false>, 256, 0) != hipSuccess || b0 < 1) b0 = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, render_kernel<true>, 256, 0) != hipSuccess || b1 < 1) b1 = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, path_kernel<false>, 256, 0) != hipSuccess || b0 < 1) b0 = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, path_kernel<true>, 256, 0) != hipSuccess || b1 < 1) b1 = 1;
     s->blocks_per_cu[0] = b0;
     s->blocks_per_cu[1] = b1;
 
