@@ -176,7 +176,7 @@ def main():
             "roofline": {
                 "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
-                "kernel": "render_kernel<false>", "kernel_ms": round(k_ms, 3),
+                "kernel": "path_kernel<false>", "kernel_ms": round(k_ms, 3),
                 "algorithmic_flops_per_sample": round(flops_ps, 1), "algorithmic_bytes_per_sample": round(bytes_ps, 1),
                 "events_per_sample": {k: round(v, 3) for k, v in per.items() if k != "samples"},
                 "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -307,6 +307,11 @@ typedef enum rt_debug_op {
 } rt_debug_op;
 int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device);
 
+/* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
+ * live lanes wait for it; box_iters = box-test rounds per scheduling decision.  Negative / zero: keep.
+ * Affects speed only, never results.  Process-wide; not for concurrent use with renders. */
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t box_iters);
+
 const char *rt_last_error(void);
 const char *rt_version(void);
 

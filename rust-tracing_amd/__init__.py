@@ -179,6 +179,7 @@ RT_AMD_SYMBOLS = {
     "rt_resolve_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_eval": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.c_int]),
+    "rt_debug_set_tuning": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
 }
@@ -243,7 +244,7 @@ def amd_lib():
     """librt_amd.so (HIP).  Loading works without a GPU; rendering does not."""
     global _amd_lib
     if _amd_lib is None:
-        path = LIB_DIR / "librt_amd.so"
+        path = Path(os.environ.get("RT_AMD_LIB", LIB_DIR / "librt_amd.so"))  # RT_AMD_LIB: tuning builds only
         if not path.exists():
             raise RtError(f"{path} is missing: the HIP renderer is not built and there is no fallback; "
                           "run `python -c 'import __graft_entry__ as g; g.build()'`")

@@ -219,9 +219,13 @@ template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, uint32_t tex, do
 // instruction stream the wave issues has most of its 64 lanes active.
 enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST_SHADE = 4, ST_DONE = 5 };
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for (tools/tune.py: 3 beats 2 and 4)
+#endif
+
 constexpr uint32_t JOBS_PER_GRAB = 1024; // jobs a wave reserves at a time (16 sample-rows of one 8x8 tile)
 
-template <bool COUNT> __global__ __launch_bounds__(256) void path_kernel(const KParams P) {
+template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_kernel(const KParams P) {
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -798,7 +802,7 @@ struct Workspace {
 // Scheduler knobs (64ths of the live lanes a deferred stage must have queued; box rounds per decision).
 // Defaults were picked on MI355X with bench.py (DESIGN.md "Scheduler"); the RT_* variables are for tuning runs.
 struct Tuning {
-    uint32_t th_prim = 16, th_other = 16, th_shade = 24, box_iters = 2;
+    uint32_t th_prim = 8, th_other = 16, th_shade = 48, box_iters = 4;
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
         auto env = [](const char *name, uint32_t &v) { if (const char *e = getenv(name)) v = (uint32_t)strtoul(e, nullptr, 10); };
@@ -807,7 +811,7 @@ struct Tuning {
         if (box_iters < 1) box_iters = 1;
     }
 };
-const Tuning &tuning() { static const Tuning t; return t; }
+Tuning &tuning() { static Tuning t; return t; }
 
 template <class T> struct DeviceArray {
     T *ptr = nullptr;
@@ -906,7 +910,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         if (out_counters) *out_counters = rt_counters{};
         return RT_OK;
     }
-    const Tuning &tn = tuning();
+    const Tuning tn = tuning();
 
     // samples per launch: bounded by the sample buffer and by the 32-bit job index
     const int64_t bytes_per_sample_row = n_local * 64 * 3 * (int64_t)sizeof(double);
@@ -1166,6 +1170,15 @@ int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count,
     hipLaunchKernelGGL(tiles_to_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, width,
                        height, tiles_x, shard_count, stride, d_gathered, d_frame);
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t box_iters) {
+    Tuning &t = tuning();
+    if (th_prim >= 0) t.th_prim = (uint32_t)th_prim;
+    if (th_other >= 0) t.th_other = (uint32_t)th_other;
+    if (th_shade >= 0) t.th_shade = (uint32_t)th_shade;
+    if (box_iters >= 1) t.box_iters = (uint32_t)box_iters;
     return RT_OK;
 }
 
