@@ -274,6 +274,9 @@ class HostScene:
         self._handle = handle
         self.desc = lib.rth_scene_desc(handle).contents
         self.camera = lib.rth_scene_camera(handle).contents
+        # the records live in the C object: keep it alive for as long as either view is referenced
+        self.desc._owner = self
+        self.camera._owner = self
 
     @property
     def width(self):

@@ -1,0 +1,84 @@
+"""The C-ABI libraries load (no GPU needed), export every symbol the headers declare, and the ctypes mirrors of
+the ABI structs have the C compiler's layout."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|int64_t|char|rt_\w+|rth_\w+)\s*\*?\s*\b((?:rt|rth)_\w+)\s*\(", re.M)
+
+
+def declared(header):
+    text = (ROOT / "include" / header).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(DECL.findall(text)))
+
+
+def exported(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], check=True, capture_output=True, text=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_librt_amd_exports_everything_rt_amd_h_declares(rt):
+    names = declared("rt_amd.h")
+    assert "rt_render" in names and "rt_scene_create" in names and len(names) >= 12
+    have = exported(rt.LIB_DIR / "librt_amd.so")
+    assert not [n for n in names if n not in have]
+    assert sorted(rt.RT_AMD_SYMBOLS) == names, "python binding table out of sync with rt_amd.h"
+    lib = rt.amd_lib()  # binds every symbol; loading must not need a GPU
+    assert lib.rt_version().startswith(b"rt_amd")
+    assert lib.rt_device_count() >= 0
+
+
+def test_librt_host_exports_everything_rt_host_h_declares(rt):
+    names = declared("rt_host.h")
+    have = exported(rt.LIB_DIR / "librt_host.so")
+    assert not [n for n in names if n not in have]
+    assert sorted(rt.RT_HOST_SYMBOLS) == names
+    rt.host_lib()
+
+
+def test_product_does_not_link_or_mention_the_oracle(rt):
+    """The oracle is a checker: the product must not depend on it."""
+    for lib in ("librt_amd.so", "librt_host.so"):
+        out = subprocess.run(["ldd", str(rt.LIB_DIR / lib)], capture_output=True, text=True).stdout
+        assert "oracle" not in out
+    for path in (ROOT / "rust-tracing_amd").rglob("*"):
+        if path.is_file() and path.suffix in (".py", ".hip", ".h", ".hpp", ".cpp") or path.name == "Makefile":
+            text = path.read_text(errors="ignore")
+            assert "oracle/" not in text and "oracle_lib" not in text and "librt_oracle" not in text, path
+
+
+def test_no_gpu_means_an_error_not_a_fallback(rt):
+    lib = rt.amd_lib()
+    if lib.rt_device_count() > 0:
+        return  # covered by the gpu tests
+    hs = rt.HostScene(4, width=16, spp=1)
+    handle = C.c_void_p()
+    assert lib.rt_scene_create(C.byref(hs.desc), 0, C.byref(handle)) == -2  # RT_ERR_NO_DEVICE
+    assert b"no CPU path" in lib.rt_last_error()
+
+
+def test_ctypes_structs_match_the_c_layout(rt, tmp_path):
+    structs = {"rt_vec3": rt.Vec3, "rt_aabb": rt.Aabb, "rt_ref": rt.Ref, "rt_sphere": rt.Sphere, "rt_quad": rt.Quad,
+               "rt_list": rt.List, "rt_translate": rt.Translate, "rt_rotate_y": rt.RotateY, "rt_bvh_node": rt.BvhNode,
+               "rt_bvh": rt.Bvh, "rt_constant_medium": rt.ConstantMedium, "rt_material": rt.Material,
+               "rt_texture": rt.Texture, "rt_perlin": rt.Perlin, "rt_image": rt.Image, "rt_scene_desc": rt.SceneDesc,
+               "rt_camera": rt.Camera, "rt_render_params": rt.RenderParams, "rt_counters": rt.Counters,
+               "rt_scene_stats": rt.SceneStats, "rth_scene_options": rt.SceneOptions}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_host.h"', "int main(void){"]
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"

@@ -1,0 +1,50 @@
+"""Pins the oracle (and with it the host-side scene / BVH / camera / output code it is fed by) to the REFERENCE:
+the two deterministic scenes whose screenshots the reference publishes must come out the same, block for block,
+up to Monte-Carlo noise.  Fixture: tests/golden/reference_screenshot_stats.json (block means of the reference's
+PNGs, made by tests/golden/make_reference_stats.py).  This is the only reference-derived ground truth that exists:
+the reference has no tests, no golden vectors and an unseedable RNG."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_screenshot_stats.json").read_text())
+
+
+def block_means(a, grid):
+    h, w, c = a.shape
+    ys = [round(k * h / grid) for k in range(grid + 1)]
+    xs = [round(k * w / grid) for k in range(grid + 1)]
+    return np.array([[a[ys[r]:ys[r + 1], xs[q]:xs[q + 1]].reshape(-1, c).mean(axis=0) for q in range(grid)] for r in range(grid)])
+
+
+def compare(sums, spp, shot, mean_tol, rms_tol, max_tol):
+    h, w = shot["height"], shot["width"]
+    # the screenshot is color_to_rgb(mean): clamp to the same range before comparing in linear space
+    lin = np.clip(sums.reshape(h, w, 3) / spp, 0.0, 0.999 ** 2.2)
+    ref_mean = np.array(shot["mean_linear"])
+    assert np.abs(lin.reshape(-1, 3).mean(axis=0) / ref_mean - 1).max() < mean_tol
+    rel = (block_means(lin, GOLD["grid"]) - np.array(shot["blocks_linear"])) / (np.array(shot["blocks_linear"]) + 0.01)
+    assert np.sqrt((rel ** 2).mean()) < rms_tol and np.abs(rel).max() < max_tol
+
+
+@pytest.mark.parametrize("name,spp", [("cornell_box", 48), ("cornell_smoke", 32)])
+def test_oracle_reproduces_the_reference_screenshot(rt, oracle, name, spp):
+    shot = GOLD["shots"][name]
+    hs = rt.HostScene(shot["scene"], spp=spp)           # in-code camera: 600x600, depth 8 (src/main.rs:406-418)
+    assert (hs.width, hs.height) == (shot["width"], shot["height"]) and hs.camera.max_depth == 8
+    sums = oracle.render(hs, rt.render_params(seed=7))
+    # 48 / 32 spp leave ~3 % noise per 50x50 block; the global mean is far tighter
+    compare(sums, spp, shot, mean_tol=0.015, rms_tol=0.04, max_tol=0.15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke"])
+def test_gpu_converged_render_matches_the_reference_screenshot(rt, gpu, name):
+    """The same pin at 2048 spp on the GPU, where the noise is small enough to hold every block to 2.5 %."""
+    shot = GOLD["shots"][name]
+    spp = 2048
+    hs = rt.HostScene(shot["scene"], spp=spp)
+    sums = rt.DeviceScene(hs).render(rt.render_params(seed=7))
+    compare(sums, spp, shot, mean_tol=0.012, rms_tol=0.012, max_tol=0.04)
