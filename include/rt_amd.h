@@ -307,10 +307,22 @@ typedef enum rt_debug_op {
 } rt_debug_op;
 int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device);
 
+/* Test hook: runs the kernel's conservative f32 box test and the exact f64 slab test on n (ray, box) pairs —
+ * rays[i] = (origin xyz, direction xyz), boxes[i] = (lo xyz, hi xyz), interval (tmin, tmax) — and reports, per pair,
+ * whether each test enters the box.  The f32 test must enter wherever the exact one does (tests/test_gpu_parity.py). */
+int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax,
+                       uint8_t *out_exact_hit, uint8_t *out_f32_hit, int device);
+
+/* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
+ * (box, sphere, quad, other, shade): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
+ * summed over waves. */
+int rt_debug_stage_profile(uint64_t out[15]);
+
 /* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
- * live lanes wait for it; box_iters = box-test rounds per scheduling decision.  Negative / zero: keep.
+ * live lanes wait for it; the box loop keeps running while th_box/64 of them are in it; use_lds = 0 forces the
+ * scene to be gathered from global memory even when it fits the LDS.  Negative: keep.
  * Affects speed only, never results.  Process-wide; not for concurrent use with renders. */
-int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t box_iters);
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds);
 
 const char *rt_last_error(void);
 const char *rt_version(void);

@@ -179,13 +179,42 @@ RT_AMD_SYMBOLS = {
     "rt_resolve_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_eval": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.c_int]),
-    "rt_debug_set_tuning": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_debug_box_tests": (C.c_int, [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                                     C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int]),
+    "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "rt_debug_set_tuning": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
 }
 
 RT_DEBUG_LOG, RT_DEBUG_SIN, RT_DEBUG_ACOS, RT_DEBUG_ATAN2, RT_DEBUG_POW5, RT_DEBUG_SQRT, RT_DEBUG_DIV, \
     RT_DEBUG_MUL_ADD, RT_DEBUG_RNG_RANDOM, RT_DEBUG_RNG_RANGE = range(1, 11)
+
+
+def debug_box_tests(rays, boxes, tmin, tmax, device=0):
+    """rt_debug_box_tests: (exact f64 test enters?, conservative f32 test enters?) per (ray, box) pair."""
+    import numpy as np
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+    n = rays.shape[0]
+    assert boxes.shape[0] == n
+    exact = np.zeros(n, dtype=np.uint8); f32 = np.zeros(n, dtype=np.uint8)
+    _check(amd_lib().rt_debug_box_tests(n, rays.ctypes.data_as(C.POINTER(C.c_double)),
+                                        boxes.ctypes.data_as(C.POINTER(C.c_double)), tmin, tmax,
+                                        exact.ctypes.data_as(C.POINTER(C.c_uint8)), f32.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                        device), "rt_debug_box_tests")
+    return exact.astype(bool), f32.astype(bool)
+
+
+def debug_stage_profile() -> dict:
+    """rt_debug_stage_profile: per stage {rounds, lanes (mean active per round), cycles} of the last counted render."""
+    buf = (C.c_uint64 * 15)()
+    _check(amd_lib().rt_debug_stage_profile(buf), "rt_debug_stage_profile")
+    out = {}
+    for i, name in enumerate(("box", "sphere", "quad", "other", "shade")):
+        rounds, lanes, cycles = int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])
+        out[name] = {"rounds": rounds, "mean_active_lanes": lanes / rounds if rounds else 0.0, "cycles": cycles}
+    return out
 
 
 def debug_eval(op, a, b=None, device=0):

@@ -16,7 +16,8 @@ struct CompileError : std::runtime_error {
 };
 
 struct CompiledScene {
-    std::vector<Node> nodes;
+    std::vector<Node> nodes;     // f64 boxes (build-time)
+    std::vector<Node32> nodes32; // what the device walks
     std::vector<Sphere> spheres;
     std::vector<Quad> quads;
     std::vector<Instance> instances;
@@ -40,6 +41,7 @@ class Compiler {
         emit_object(d_.world, nullptr, -1, false, 0);
         if (out_.nodes.empty()) throw CompileError(RT_ERR_INVALID_ARGUMENT, "scene has no geometry");
         if (out_.nodes.size() > 0x3fffffffu) throw CompileError(RT_ERR_UNSUPPORTED, "too many nodes");
+        pack_nodes();
         out_.materials.assign(d_.materials, d_.materials + d_.n_materials);
         out_.textures.assign(d_.textures, d_.textures + d_.n_textures);
         if (d_.n_perlins) out_.perlins.assign(d_.perlins, d_.perlins + d_.n_perlins);
@@ -64,6 +66,34 @@ class Compiler {
   private:
     const rt_scene_desc &d_;
     CompiledScene out_;
+
+    // f64 -> f32 rounded towards -inf / +inf
+    static float round_down(double x) {
+        float f = (float)x;
+        if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+        return f;
+    }
+    static float round_up(double x) {
+        float f = (float)x;
+        if ((double)f < x) f = std::nextafterf(f, INFINITY);
+        return f;
+    }
+    void pack_nodes() {
+        out_.nodes32.resize(out_.nodes.size());
+        for (size_t i = 0; i < out_.nodes.size(); ++i) {
+            const Node &n = out_.nodes[i];
+            Node32 &m = out_.nodes32[i];
+            m.bx[0] = round_down(n.lo[0]); m.bx[1] = round_up(n.hi[0]);
+            m.by[0] = round_down(n.lo[1]); m.by[1] = round_up(n.hi[1]);
+            m.bz[0] = round_down(n.lo[2]); m.bz[1] = round_up(n.hi[2]);
+            m.skip = n.skip;
+            const uint32_t kind = n.kind & NODE_KIND_MASK;
+            const uint32_t count = (kind == NK_SPHERES || kind == NK_QUADS) ? n.b : 0u;
+            if (count > N32_MAX_COUNT || n.a > N32_MAX_A)
+                throw CompileError(RT_ERR_UNSUPPORTED, "rt_scene_create: scene exceeds the packed record limits");
+            m.packed = kind | ((n.kind & NODE_NO_BBOX) ? N32_NO_BBOX : 0u) | (count << N32_COUNT_SHIFT) | (n.a << N32_A_SHIFT);
+        }
+    }
 
     [[noreturn]] static void bad(const std::string &m) { throw CompileError(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: " + m); }
 
@@ -207,8 +237,14 @@ class Compiler {
                         if (j == i) first = id;
                         ++j;
                     }
-                    close(push_node(k0 == RT_HITTABLE_QUAD ? NK_QUADS : NK_SPHERES, single_run ? bbox : nullptr, first,
-                                    (uint32_t)(j - i)));
+                    // one leaf record holds at most N32_MAX_COUNT primitives; a longer run continues in the next record
+                    // (the box, if any, is simply tested again)
+                    for (uint32_t done = 0, total = (uint32_t)(j - i); done < total;) {
+                        const uint32_t take = total - done > N32_MAX_COUNT ? N32_MAX_COUNT : total - done;
+                        close(push_node(k0 == RT_HITTABLE_QUAD ? NK_QUADS : NK_SPHERES, single_run ? bbox : nullptr,
+                                        first + done, take));
+                        done += take;
+                    }
                     i = j;
                 } else {
                     emit_object(d_.list_items[l.first + i], nullptr, cur_inst, in_medium, depth + 1);
@@ -278,6 +314,7 @@ class Compiler {
             const uint32_t id = (uint32_t)out_.media.size() - 1u;
             uint32_t enter = push_node(NK_MEDIUM_ENTER, bbox, id, 0);
             const uint32_t first_child = (uint32_t)out_.nodes.size();
+            out_.media[id].first_node = first_child;
             emit_object(m.boundary, nullptr, cur_inst, true, depth + 1);
             need(out_.nodes.size() > first_child, "medium boundary is empty");
             close(push_node(NK_MEDIUM_EXIT, nullptr, id, first_child));

@@ -45,7 +45,7 @@ struct DMaterial { // 64 bytes
 static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 
 struct KParams {
-    const Node *nodes;
+    const Node32 *nodes;
     const Sphere *spheres;
     const Quad *quads;
     const Instance *insts;
@@ -60,7 +60,7 @@ struct KParams {
     double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
     double *att_stack;              // [max_depth][n_threads][3]: attenuations of the current path
     uint32_t *job_counter;
-    unsigned long long *counters;   // rt_counters as 10 u64, or null
+    unsigned long long *counters;   // rt_counters as 10 u64, then per stage (5): rounds, active lanes, cycles; or null
     rt_camera cam;
     uint64_t seed_mixed;            // mix64(seed + gamma)
     uint32_t n_nodes;
@@ -73,7 +73,12 @@ struct KParams {
     int32_t tiles_x;
     uint32_t n_local_tiles;
     uint32_t th_prim, th_other, th_shade; // scheduler thresholds, in 64ths of the live lanes
-    uint32_t box_iters;             // box-test rounds per scheduler decision
+    uint32_t th_box;                // the box loop keeps running while this many 64ths of the live lanes are in it
+    // LDS-resident scene (SCENE_IN_LDS kernels): image to copy in, and where its parts start (bytes)
+    const uint4 *lds_image;
+    uint32_t lds_image_bytes;
+    uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
+    uint32_t lds_off_world;         // per-thread world-ray slots: [6][blockDim.x] doubles
 };
 
 struct Counts {
@@ -225,20 +230,113 @@ enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST
 
 constexpr uint32_t JOBS_PER_GRAB = 1024; // jobs a wave reserves at a time (16 sample-rows of one 8x8 tile)
 
-template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_kernel(const KParams P) {
+// What one box-stage round needs of a record
+struct NodeData {
+    float lo[3], hi[3];
+    uint32_t skip, packed;
+};
+
+// SCENE_IN_LDS: the node, sphere and quad tables are copied into the CU's LDS once per workgroup and every lane
+// gathers from there (divergent 16-byte reads: ~10x lower latency than L1 and no tag-lookup serialisation).
+// LDS image: node_a[N] = (x.lo, x.hi, y.lo, y.hi) | node_b[N] = (z.lo, z.hi, skip, packed) | spheres (64 B) |
+// quads (144 B).  The two halves of a node record are separate tables so that lanes reading the same half of
+// different records spread over all 16 four-bank slots (a 32-byte record stride would use only 8).
+template <bool LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned char *lds, uint32_t id) {
+    float4 a, b;
+    if constexpr (LDS) {
+        a = reinterpret_cast<const float4 *>(lds)[id];
+        b = reinterpret_cast<const float4 *>(lds + P.lds_off_node_b)[id];
+    } else {
+        const float4 *np = reinterpret_cast<const float4 *>(&P.nodes[id]);
+        a = np[0];
+        b = np[1];
+    }
+    NodeData n;
+    n.lo[0] = a.x; n.hi[0] = a.y; n.lo[1] = a.z; n.hi[1] = a.w; n.lo[2] = b.x; n.hi[2] = b.y;
+    n.skip = __float_as_uint(b.z);
+    n.packed = __float_as_uint(b.w);
+    return n;
+}
+
+// f32 copies of a ray for the conservative box test: origin, 1/d, and the bound E on how far rounding the origin
+// to f32 can move a slab distance; `degenerate`: some 1/d or E is not finite -> every box is entered.
+struct Ray32 {
+    float ox, oy, oz, ix, iy, iz, ex, ey, ez;
+    bool degenerate;
+};
+RT_DEV Ray32 make_ray32(V3 o, V3 d) {
+    Ray32 r;
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    // 1/d is the reference's per-visit quotient (src/aabb.rs:66), rounded once more to f32
+    r.ix = (float)(1.0 / d.x); r.iy = (float)(1.0 / d.y); r.iz = (float)(1.0 / d.z);
+    // |o - o32| <= 2^-24 |o|, i.e. at most 2^-24 |o| |1/d| in t; E carries a 4x margin
+    r.ex = __builtin_fabsf(r.ox * r.ix) * 0x1p-22f;
+    r.ey = __builtin_fabsf(r.oy * r.iy) * 0x1p-22f;
+    r.ez = __builtin_fabsf(r.oz * r.iz) * 0x1p-22f;
+    const float fsum = (r.ex + r.ey + r.ez) + (__builtin_fabsf(r.ix) + __builtin_fabsf(r.iy) + __builtin_fabsf(r.iz));
+    r.degenerate = !(fsum < __builtin_inff()); // an inf or a NaN anywhere
+    return r;
+}
+// Conservative f32 slab test.  The exact test (f64, interval narrowed axis by axis; equivalent to the reference's
+// un-narrowed one, DESIGN.md "Box test") passes iff max(near) < min(far) over the three slabs and (tmin, tmax).
+// Here: boxes are rounded outward, E bounds the effect of rounding the origin, and the final interval is widened by
+// 2^-21 relative (> the three roundings of 2^-24 in (b - o) * (1/d) plus the conversions of 1/d, tmin and tmax).
+// So this test passes whenever the exact one does; when it passes although the exact one would not, the visit
+// finds nothing (primitives are intersected in f64).  A record without a box carries (-inf, +inf): always passes.
+RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, float tmin32, float tmax32) {
+    const float t0x = (lo[0] - r.ox) * r.ix, t1x = (hi[0] - r.ox) * r.ix;
+    const float t0y = (lo[1] - r.oy) * r.iy, t1y = (hi[1] - r.oy) * r.iy;
+    const float t0z = (lo[2] - r.oz) * r.iz, t1z = (hi[2] - r.oz) * r.iz;
+    const float nx = __builtin_fminf(t0x, t1x) - r.ex, fx = __builtin_fmaxf(t0x, t1x) + r.ex;
+    const float ny = __builtin_fminf(t0y, t1y) - r.ey, fy = __builtin_fmaxf(t0y, t1y) + r.ey;
+    const float nz = __builtin_fminf(t0z, t1z) - r.ez, fz = __builtin_fmaxf(t0z, t1z) + r.ez;
+    const float enter = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin32));
+    const float leave = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tmax32));
+    const float lb = enter - __builtin_fabsf(enter) * 0x1p-21f;
+    const float ub = leave + __builtin_fabsf(leave) * 0x1p-21f;
+    return !r.degenerate && lb > ub; // a NaN compares false: pass
+}
+// The exact f64 test the kernel used before (and the oracle's tight mode): kept as the yardstick for the test hook
+RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, double tmin, double tmax) {
+    const double od[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    for (int ax = 0; ax < 3; ++ax) {
+        const double inv = 1.0 / dd[ax];
+        double t0 = (lo[ax] - od[ax]) * inv, t1 = (hi[ax] - od[ax]) * inv;
+        if (inv < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
+        tmin = __builtin_fmax(t0, tmin);
+        tmax = __builtin_fmin(t1, tmax);
+        if (tmax <= tmin) return true;
+    }
+    return false;
+}
+
+template <bool COUNT, bool LDS, int THREADS>
+__global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree)
-    __shared__ double lds_world[6][256];
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    if constexpr (LDS) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (uint32_t k = threadIdx.x; k < P.lds_image_bytes / 16u; k += THREADS) dst[k] = P.lds_image[k];
+        __syncthreads();
+    }
+    const Sphere *const sphere_tab = LDS ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
+    const Quad *const quad_tab = LDS ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
+    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree): [6][THREADS]
+    double *const lds_world = reinterpret_cast<double *>(lds_raw + P.lds_off_world);
 
     Counts cn{};
     Rng rng;
     rng.state = 0;
 
     // ---- per-lane path state ----
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 0); // current-frame ray, 1/d
-    double a = 1.0, time = 0.0;                              // |d|^2 (Sphere::hit's `a`), ray time
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1); // current-frame ray
+    double a = 1.0, time = 0.0;          // |d|^2 (Sphere::hit's `a`), ray time
+    // f32 copies for the conservative box test: origin, 1/d, and the bound E on what rounding the origin to f32
+    // can move a slab distance (see the box stage); `degenerate`: some 1/d or E is not finite -> enter every box
+    Ray32 r32 = make_ray32(o, d);
+    float tmin32 = 0, tmax32 = 0;
     uint32_t job = 0;
     int32_t depth = 0;
     uint32_t n_att = 0;
@@ -262,7 +360,23 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
     const uint32_t n_nodes = P.n_nodes;
     const int32_t w = P.cam.image_width, h = P.cam.image_height;
 
+    auto refresh_ray32 = [&]() { r32 = make_ray32(o, d); };
+    auto refresh_interval32 = [&]() {
+        tmin32 = (float)cur_tmin;
+        tmax32 = (float)cur_tmax;
+    };
+
+    // COUNT only: per stage, rounds run / lanes active in them / shader cycles spent (wave-level, kept by lane 0)
+    unsigned long long prof_rounds[5] = {0, 0, 0, 0, 0}, prof_lanes[5] = {0, 0, 0, 0, 0}, prof_cycles[5] = {0, 0, 0, 0, 0};
+    unsigned long long t_prev = COUNT ? __builtin_amdgcn_s_memtime() : 0;
+    uint32_t prev_run = ST_SHADE;
+
     for (;;) {
+        if (COUNT) {
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            prof_cycles[prev_run] += t_now - t_prev;
+            t_prev = t_now;
+        }
         // ---------------- scheduler: which stage has enough lanes queued? ----------------
         const uint32_t c_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
         const uint32_t c_sph = (uint32_t)__popcll(__ballot(stage == ST_SPHERE));
@@ -284,49 +398,30 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
             if (c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
         }
 
+        if (COUNT) {
+            prev_run = run;
+            prof_rounds[run] += 1;
+            prof_lanes[run] += run == ST_BOX ? c_box : run == ST_SPHERE ? c_sph : run == ST_QUAD ? c_quad : run == ST_OTHER ? c_oth : c_shade;
+        }
         if (run == ST_BOX) {
             // ---------------- box test + dispatch on the record kind ----------------
-#pragma unroll 1
-            for (uint32_t it = 0; it < P.box_iters; ++it) {
+            // stays in this loop (one ballot per round) while enough of the wave's live lanes are walking boxes
+            uint32_t in_box;
+            do {
                 if (stage == ST_BOX) {
-                    const Node *np = &P.nodes[node];
-                    const uint32_t kflags = np->kind;
-                    const uint32_t skip = np->skip;
-                    bool miss = false;
-                    if (!(kflags & NODE_NO_BBOX)) {
-                        if (COUNT) cn.node_visits++;
-                        // slab test with the interval narrowed axis by axis (DESIGN.md "Box test": cannot change a
-                        // result relative to the reference's un-narrowed test, src/aabb.rs:64-84)
-                        double tmin = cur_tmin, tmax = cur_tmax;
-                        {
-                            double t0 = (np->lo[0] - o.x) * inv.x, t1 = (np->hi[0] - o.x) * inv.x;
-                            if (inv.x < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-                            tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
-                            miss = tmax <= tmin;
-                        }
-                        {
-                            double t0 = (np->lo[1] - o.y) * inv.y, t1 = (np->hi[1] - o.y) * inv.y;
-                            if (inv.y < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-                            tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
-                            miss = miss || tmax <= tmin;
-                        }
-                        {
-                            double t0 = (np->lo[2] - o.z) * inv.z, t1 = (np->hi[2] - o.z) * inv.z;
-                            if (inv.z < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-                            tmin = __builtin_fmax(t0, tmin); tmax = __builtin_fmin(t1, tmax);
-                            miss = miss || tmax <= tmin;
-                        }
-                    }
+                    const NodeData nd = load_node<LDS>(P, lds_raw, node);
+                    if (COUNT) cn.node_visits += (nd.packed & N32_NO_BBOX) ? 0u : 1u;
+                    const bool miss = box_miss_f32(nd.lo, nd.hi, r32, tmin32, tmax32);
                     if (miss) {
-                        node = skip;
+                        node = nd.skip;
                     } else {
-                        const uint32_t kind = kflags & NODE_KIND_MASK;
+                        const uint32_t kind = nd.packed & N32_KIND_MASK;
                         if (kind == NK_INNER) {
                             node = node + 1;
                         } else if (kind == NK_SPHERES || kind == NK_QUADS) {
-                            prim_cur = np->a;
-                            prim_end = prim_cur + np->b;
-                            node = skip; // where the walk continues after the leaf's primitives
+                            prim_cur = nd.packed >> N32_A_SHIFT;
+                            prim_end = prim_cur + ((nd.packed >> N32_COUNT_SHIFT) & N32_COUNT_MASK);
+                            node = nd.skip; // where the walk continues after the leaf's primitives
                             stage = kind == NK_SPHERES ? ST_SPHERE : ST_QUAD;
                         } else {
                             stage = ST_OTHER;
@@ -334,13 +429,15 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
                     }
                     if (stage == ST_BOX && node >= n_nodes) stage = ST_SHADE;
                 }
-            }
+                in_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
+                if (COUNT && in_box * 64u >= P.th_box * live && in_box > 0) { prof_rounds[ST_BOX] += 1; prof_lanes[ST_BOX] += in_box; }
+            } while (in_box * 64u >= P.th_box * live && in_box > 0);
         } else if (run == ST_SPHERE) {
             // ---------------- Sphere::hit (src/sphere.rs:58-83), one sphere per round ----------------
             if (stage == ST_SPHERE) {
                 if (COUNT) cn.sphere_tests++;
                 const uint32_t q = prim_cur;
-                const Sphere *s = &P.spheres[q];
+                const Sphere *s = &sphere_tab[q];
                 V3 center = ld3(s->center);
                 if (s->is_moving) center = center + ld3(s->center_vec) * time;
                 const V3 oc = o - center;
@@ -357,6 +454,7 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
                     }
                     if (ok) {
                         cur_tmax = root;
+                        tmax32 = (float)root;
                         if ((mode & 3u) == 0) { best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
                         else mode |= 0x100u;
                     }
@@ -369,7 +467,7 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
             if (stage == ST_QUAD) {
                 if (COUNT) cn.quad_tests++;
                 const uint32_t q = prim_cur;
-                const Quad *qd = &P.quads[q];
+                const Quad *qd = &quad_tab[q];
                 const V3 normal = ld3(qd->normal);
                 const double denom = dot(normal, d);
                 if (!(__builtin_fabs(denom) < 1e-8)) {
@@ -382,6 +480,7 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
                         const double beta = dot(qw, cross(ld3(qd->u), php));
                         if (!(alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0)) {
                             cur_tmax = t;
+                            tmax32 = (float)t;
                             if ((mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
                             else mode |= 0x100u;
                         }
@@ -393,22 +492,22 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
         } else if (run == ST_OTHER) {
             // ---------------- frame changes and ConstantMedium steps ----------------
             if (stage == ST_OTHER) {
-                const Node *np = &P.nodes[node];
-                const uint32_t kind = np->kind & NODE_KIND_MASK;
-                const uint32_t na = np->a;
+                const NodeData nd = load_node<LDS>(P, lds_raw, node);
+                const uint32_t kind = nd.packed & N32_KIND_MASK;
+                const uint32_t na = nd.packed >> N32_A_SHIFT;
                 if (kind == NK_INST_ENTER) {
                     if (COUNT) cn.instance_enters++;
                     if (cur_inst < 0) { // leaving the world frame: park the world ray
-                        lds_world[0][threadIdx.x] = o.x; lds_world[1][threadIdx.x] = o.y; lds_world[2][threadIdx.x] = o.z;
-                        lds_world[3][threadIdx.x] = d.x; lds_world[4][threadIdx.x] = d.y; lds_world[5][threadIdx.x] = d.z;
+                        lds_world[0 * THREADS + threadIdx.x] = o.x; lds_world[1 * THREADS + threadIdx.x] = o.y; lds_world[2 * THREADS + threadIdx.x] = o.z;
+                        lds_world[3 * THREADS + threadIdx.x] = d.x; lds_world[4 * THREADS + threadIdx.x] = d.y; lds_world[5 * THREADS + threadIdx.x] = d.z;
                     }
                     apply_instance(P.insts[na], o, d);
                     cur_inst = (int32_t)na;
                     node = node + 1;
                 } else if (kind == NK_INST_EXIT) {
                     cur_inst = P.insts[na].parent;
-                    o = v3(lds_world[0][threadIdx.x], lds_world[1][threadIdx.x], lds_world[2][threadIdx.x]);
-                    d = v3(lds_world[3][threadIdx.x], lds_world[4][threadIdx.x], lds_world[5][threadIdx.x]);
+                    o = v3(lds_world[0 * THREADS + threadIdx.x], lds_world[1 * THREADS + threadIdx.x], lds_world[2 * THREADS + threadIdx.x]);
+                    d = v3(lds_world[3 * THREADS + threadIdx.x], lds_world[4 * THREADS + threadIdx.x], lds_world[5 * THREADS + threadIdx.x]);
                     ray_to_frame(P.insts, cur_inst, o, d);
                     node = node + 1;
                 } else if (kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
@@ -445,7 +544,7 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
                         }
                     }
                     if (again) {
-                        node = np->b;
+                        node = P.media[na].first_node;
                     } else {
                         mode = 0;
                         cur_tmin = 0.001;
@@ -454,8 +553,10 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
                     }
                 }
                 if (kind == NK_INST_ENTER || kind == NK_INST_EXIT) {
-                    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                    refresh_ray32();
                     a = len2(d);
+                } else {
+                    refresh_interval32();
                 }
                 stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
@@ -483,14 +584,14 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
                     const uint32_t pk = best_prim & PRIM_KIND_MASK, pi = best_prim & PRIM_INDEX_MASK;
                     bool uv_from_sphere = false;
                     if (pk == PRIM_SPHERE) { // src/sphere.rs:85-88
-                        const Sphere *s = &P.spheres[pi];
+                        const Sphere *s = &sphere_tab[pi];
                         V3 center = ld3(s->center);
                         if (s->is_moving) center = center + ld3(s->center_vec) * time;
                         outward_normal = div(p - center, s->radius);
                         mat = s->material;
                         uv_from_sphere = true;
                     } else if (pk == PRIM_QUAD) { // src/quad.rs:118-132
-                        const Quad *qd = &P.quads[pi];
+                        const Quad *qd = &quad_tab[pi];
                         outward_normal = ld3(qd->normal);
                         mat = qd->material;
                         if (P.mats[mat].needs_uv) {
@@ -656,9 +757,10 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
             // ---- start the closest-hit query of the next ray ----
             if (shading && stage == ST_SHADE && !need_job) {
                 if (COUNT) cn.rays++;
-                inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); // AABB::hit divides per visit (src/aabb.rs:66): same quotient
                 a = len2(d);
                 cur_tmin = 0.001; cur_tmax = INF; // (0.001, inf) (src/renderer.rs:144)
+                refresh_ray32();
+                refresh_interval32();
                 best_t = INF; best_prim = PRIM_NONE; best_inst = -1; cur_inst = -1;
                 mode = 0;
                 node = 0;
@@ -676,6 +778,13 @@ template <bool COUNT> __global__ __launch_bounds__(256, RT_MIN_WAVES) void path_
             unsigned long long v = vals[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&P.counters[q], v);
+        }
+        if (lane == 0) {
+            for (int q = 0; q < 5; ++q) {
+                atomicAdd(&P.counters[10 + q * 3 + 0], prof_rounds[q]);
+                atomicAdd(&P.counters[10 + q * 3 + 1], prof_lanes[q]);
+                atomicAdd(&P.counters[10 + q * 3 + 2], prof_cycles[q]);
+            }
         }
     }
 }
@@ -735,6 +844,24 @@ __global__ void resolve_rgb8_kernel(int64_t n_values, double inv_spp, const doub
     rgb[idx] = b;
 }
 
+// test hook: the conservative f32 box test against the exact f64 one on caller-supplied rays and boxes
+__global__ void debug_box_kernel(int64_t n, const double *__restrict__ rays, const double *__restrict__ boxes, double tmin,
+                                 double tmax, uint8_t *__restrict__ exact_hit, uint8_t *__restrict__ f32_hit) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double *r = rays + idx * 6, *b = boxes + idx * 6;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    const double lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
+    // outward rounding exactly as the scene compiler does it
+    float lo32[3], hi32[3];
+    for (int k = 0; k < 3; ++k) {
+        lo32[k] = __double2float_rd(lo[k]);
+        hi32[k] = __double2float_ru(hi[k]);
+    }
+    exact_hit[idx] = box_miss_f64(lo, hi, o, d, tmin, tmax) ? 0 : 1;
+    f32_hit[idx] = box_miss_f32(lo32, hi32, make_ray32(o, d), (float)tmin, (float)tmax) ? 0 : 1;
+}
+
 // test hook: evaluates one device-side scalar function over arrays (rt_debug_eval)
 __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                   double *__restrict__ out) {
@@ -770,6 +897,8 @@ __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restric
 namespace {
 
 thread_local std::string g_last_error;
+std::mutex g_stage_profile_mu;
+unsigned long long g_stage_profile[15] = {0}; // of the last counted render: 5 stages x (rounds, active lanes, cycles)
 
 uint64_t rtk_host_mix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
@@ -802,13 +931,14 @@ struct Workspace {
 // Scheduler knobs (64ths of the live lanes a deferred stage must have queued; box rounds per decision).
 // Defaults were picked on MI355X with bench.py (DESIGN.md "Scheduler"); the RT_* variables are for tuning runs.
 struct Tuning {
-    uint32_t th_prim = 8, th_other = 16, th_shade = 48, box_iters = 4;
+    uint32_t th_prim = 8, th_other = 16, th_shade = 48, th_box = 40;
+    int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
         auto env = [](const char *name, uint32_t &v) { if (const char *e = getenv(name)) v = (uint32_t)strtoul(e, nullptr, 10); };
-        env("RT_TH_PRIM", th_prim); env("RT_TH_OTHER", th_other); env("RT_TH_SHADE", th_shade); env("RT_BOX_ITERS", box_iters);
+        env("RT_TH_PRIM", th_prim); env("RT_TH_OTHER", th_other); env("RT_TH_SHADE", th_shade); env("RT_TH_BOX", th_box);
+        if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
         if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
-        if (box_iters < 1) box_iters = 1;
     }
 };
 Tuning &tuning() { static Tuning t; return t; }
@@ -823,8 +953,12 @@ template <class T> struct DeviceArray {
 struct rt_scene {
     int device = 0;
     int n_cus = 0;
-    int blocks_per_cu[2] = {0, 0}; // plain / counted kernel
-    DeviceArray<Node> nodes;
+    int blocks_per_cu[2][2] = {{0, 0}, {0, 0}}; // [scene in LDS?][counted?]
+    DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
+    uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
+    bool has_instances = false;
+    bool lds_fits = false;
+    DeviceArray<Node32> nodes;
     DeviceArray<Sphere> spheres;
     DeviceArray<Quad> quads;
     DeviceArray<Instance> insts;
@@ -843,6 +977,20 @@ struct rt_scene {
 };
 
 namespace {
+
+constexpr int GLOBAL_THREADS = 256;             // scene gathered from global memory: 256-thread blocks
+constexpr int LDS_THREADS = 768;                // scene in LDS: one 12-wave workgroup per CU shares the copy
+constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
+
+const void *kernel_for(bool lds, bool counted) {
+    if (lds) return counted ? (const void *)path_kernel<true, true, LDS_THREADS> : (const void *)path_kernel<false, true, LDS_THREADS>;
+    return counted ? (const void *)path_kernel<true, false, GLOBAL_THREADS> : (const void *)path_kernel<false, false, GLOBAL_THREADS>;
+}
+size_t dynamic_lds_bytes(const rt_scene *s, bool lds) {
+    const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+    const size_t world = (lds && !s->has_instances) ? 0 : (size_t)6 * threads * sizeof(double);
+    return (lds ? s->lds_image_bytes : 0) + world;
+}
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
     dst.bytes = src.size() * sizeof(T);
@@ -873,7 +1021,7 @@ void free_scene(rt_scene *s) {
     }
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
-    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr);
     delete s;
 }
 
@@ -920,11 +1068,14 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     if (chunk > n_samples_total) chunk = n_samples_total;
     if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
 
-    const int threads = 256;
-    const int bpc = scene->blocks_per_cu[counted ? 1 : 0];
+    const bool lds = scene->lds_fits && tn.use_lds != 0;
+    const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+    const int bpc = scene->blocks_per_cu[lds ? 1 : 0][counted ? 1 : 0];
+    const size_t dyn_lds = dynamic_lds_bytes(scene, lds);
     // persistent grid: every resident wave pulls jobs until none are left
     int64_t grid = (int64_t)scene->n_cus * bpc;
-    const int64_t max_useful = (n_local * 64 * chunk + JOBS_PER_GRAB * 4 - 1) / (JOBS_PER_GRAB * 4);
+    const int64_t waves_per_block = threads / 64;
+    const int64_t max_useful = (n_local * 64 * chunk + JOBS_PER_GRAB * waves_per_block - 1) / (JOBS_PER_GRAB * waves_per_block);
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
     const uint32_t n_threads = (uint32_t)(grid * threads);
@@ -949,10 +1100,10 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             w.sample_bytes = need_samples;
         }
         if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
-        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 10 * sizeof(unsigned long long)));
+        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 25 * sizeof(unsigned long long)));
         ws = w;
     }
-    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 10 * sizeof(unsigned long long), stream));
+    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 25 * sizeof(unsigned long long), stream));
 
     KParams K{};
     K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
@@ -971,9 +1122,13 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
     K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
     K.n_local_tiles = (uint32_t)n_local;
-    K.th_prim = tn.th_prim; K.th_other = tn.th_other; K.th_shade = tn.th_shade; K.box_iters = tn.box_iters;
+    K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds ? scene->lds_image_bytes : 0;
+    K.lds_off_node_b = scene->lds_off_node_b;
+    K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
+    K.lds_off_world = lds ? scene->lds_image_bytes : 0;
+    K.th_prim = tn.th_prim; K.th_other = tn.th_other; K.th_shade = tn.th_shade; K.th_box = tn.th_box;
 
-    const unsigned sum_grid = (unsigned)((n_local * 64 + threads - 1) / threads);
+    const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
     for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk) {
         const int64_t ns = (p.sample_end - sb) < chunk ? (p.sample_end - sb) : chunk;
         K.sample_begin = (int32_t)sb;
@@ -981,17 +1136,26 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
-        if (counted) hipLaunchKernelGGL(path_kernel<true>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
-        else hipLaunchKernelGGL(path_kernel<false>, dim3((unsigned)grid), dim3(threads), 0, stream, K);
+        if (lds) {
+            if (counted) hipLaunchKernelGGL((path_kernel<true, true, LDS_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
+            else hipLaunchKernelGGL((path_kernel<false, true, LDS_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
+        } else {
+            if (counted) hipLaunchKernelGGL((path_kernel<true, false, GLOBAL_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
+            else hipLaunchKernelGGL((path_kernel<false, false, GLOBAL_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
+        }
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(threads), 0, stream, K);
+        hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(256), 0, stream, K);
         HIP_TRY(hipGetLastError());
     }
 
     if (counted) {
-        unsigned long long host[10];
+        unsigned long long host[25];
         HIP_TRY(hipMemcpyAsync(host, ws.counters, sizeof host, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        {
+            std::lock_guard<std::mutex> lock(g_stage_profile_mu);
+            for (int q = 0; q < 15; ++q) g_stage_profile[q] = host[10 + q];
+        }
         out_counters->samples = host[0]; out_counters->rays = host[1]; out_counters->node_visits = host[2];
         out_counters->sphere_tests = host[3]; out_counters->quad_tests = host[4]; out_counters->medium_visits = host[5];
         out_counters->rng_draws = host[6]; out_counters->noise_evals = host[7]; out_counters->image_lookups = host[8];
@@ -1043,11 +1207,42 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "hipGetDeviceProperties failed"); }
     s->n_cus = prop.multiProcessorCount;
-    int b0 = 0, b1 = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, path_kernel<false>, 256, 0) != hipSuccess || b0 < 1) b0 = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, path_kernel<true>, 256, 0) != hipSuccess || b1 < 1) b1 = 1;
-    s->blocks_per_cu[0] = b0;
-    s->blocks_per_cu[1] = b1;
+    s->has_instances = !cs.instances.empty();
+    // LDS image (see load_node): the two halves of the node records as separate tables, then spheres and quads
+    {
+        const size_t n = cs.nodes32.size();
+        const size_t off_b = n * 16, off_sph = n * 32;
+        const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
+        const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
+        const size_t world = s->has_instances ? (size_t)6 * LDS_THREADS * sizeof(double) : 0;
+        s->lds_fits = total + world <= LDS_BUDGET_BYTES;
+        if (s->lds_fits) {
+            std::vector<uint4> img(total / 16);
+            unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
+            for (size_t i = 0; i < n; ++i) {
+                memcpy(base + i * 16, &cs.nodes32[i], 16);
+                memcpy(base + off_b + i * 16, reinterpret_cast<const unsigned char *>(&cs.nodes32[i]) + 16, 16);
+            }
+            if (!cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
+            if (!cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
+            int urc = upload(s->lds_image, img);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+            s->lds_off_node_b = (uint32_t)off_b;
+            s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;
+            s->lds_image_bytes = (uint32_t)total;
+        }
+    }
+    for (int lds = 0; lds < 2; ++lds)
+        for (int counted = 0; counted < 2; ++counted) {
+            if (lds && !s->lds_fits) { s->blocks_per_cu[lds][counted] = 0; continue; }
+            const void *fn = kernel_for(lds != 0, counted != 0);
+            const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+            const size_t dyn = dynamic_lds_bytes(s, lds != 0);
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            int b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
+            s->blocks_per_cu[lds][counted] = b;
+        }
 
     std::vector<DMaterial> mats(cs.materials.size());
     for (size_t i = 0; i < mats.size(); ++i) {
@@ -1063,7 +1258,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     }
 
     int rc = RT_OK;
-    if ((rc = upload(s->nodes, cs.nodes)) != RT_OK || (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
+    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
         (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
         (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
         (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
@@ -1080,7 +1275,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     st.n_nodes = (uint32_t)cs.nodes.size(); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
     st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
     st.max_instance_depth = cs.max_instance_depth;
-    st.lds_nodes = 0; st.lds_bytes = 0;
+    st.lds_nodes = s->lds_fits ? (uint32_t)cs.nodes.size() : 0; st.lds_bytes = s->lds_fits ? s->lds_image_bytes : 0;
     *out_scene = s;
     return RT_OK;
 }
@@ -1173,13 +1368,48 @@ int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count,
     return RT_OK;
 }
 
-int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t box_iters) {
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds) {
     Tuning &t = tuning();
     if (th_prim >= 0) t.th_prim = (uint32_t)th_prim;
     if (th_other >= 0) t.th_other = (uint32_t)th_other;
     if (th_shade >= 0) t.th_shade = (uint32_t)th_shade;
-    if (box_iters >= 1) t.box_iters = (uint32_t)box_iters;
+    if (th_box >= 0) t.th_box = (uint32_t)th_box;
+    if (use_lds >= 0) t.use_lds = use_lds;
     return RT_OK;
+}
+
+int rt_debug_stage_profile(uint64_t out[15]) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
+    std::lock_guard<std::mutex> lock(g_stage_profile_mu);
+    for (int q = 0; q < 15; ++q) out[q] = g_stage_profile[q];
+    return RT_OK;
+}
+
+int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *out_exact_hit,
+                       uint8_t *out_f32_hit, int device) {
+    if (n <= 0 || !rays || !boxes || !out_exact_hit || !out_f32_hit) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_box_tests: bad argument");
+    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_box_tests: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *dr = nullptr, *db = nullptr;
+    uint8_t *de = nullptr, *df = nullptr;
+    const size_t bytes = (size_t)n * 6 * sizeof(double);
+    int rc = RT_OK;
+    do {
+        if (hipMalloc((void **)&dr, bytes) != hipSuccess || hipMalloc((void **)&db, bytes) != hipSuccess ||
+            hipMalloc((void **)&de, (size_t)n) != hipSuccess || hipMalloc((void **)&df, (size_t)n) != hipSuccess) {
+            rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_box_tests: hipMalloc failed"); break;
+        }
+        if (hipMemcpy(dr, rays, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, boxes, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_debug_box_tests: upload failed"); break;
+        }
+        hipLaunchKernelGGL(debug_box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, dr, db, tmin, tmax, de, df);
+        if (hipMemcpy(out_exact_hit, de, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_f32_hit, df, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_debug_box_tests: download failed"); break;
+        }
+    } while (0);
+    (void)hipFree(dr); (void)hipFree(db); (void)hipFree(de); (void)hipFree(df);
+    return rc;
 }
 
 int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device) {

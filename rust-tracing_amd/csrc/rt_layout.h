@@ -26,8 +26,8 @@ constexpr uint32_t NODE_KIND_MASK = 0xffu;
 constexpr uint32_t NODE_NO_BBOX = 0x100u; // the reference performs no box test here (object inside a list /
                                           // instance / medium): always enter
 
-// 64 bytes: four 16-byte loads per lane
-struct alignas(64) Node {
+// Build-time record (f64 box, as the reference holds it)
+struct Node {
     double lo[3];
     double hi[3];
     uint32_t skip;
@@ -35,7 +35,19 @@ struct alignas(64) Node {
     uint32_t a;
     uint32_t b;
 };
-static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
+
+// Device record, 32 bytes = two 16-byte loads per lane.  The box is held in f32, rounded OUTWARD (lo down, hi up),
+// and tested with an error-bounded f32 slab test that can only err towards "hit" (rt_kernel.hip, box stage):
+// a false positive costs a wasted visit and can never change a result (DESIGN.md "Box test"), a false negative
+// cannot happen.  Primitives are always intersected in f64.
+struct alignas(32) Node32 {
+    float bx[2], by[2], bz[2]; // (lo, hi) per axis
+    uint32_t skip;
+    uint32_t packed;           // kind (4 bits) | NO_BBOX (bit 4) | count (7 bits, from bit 5) | a (20 bits, from bit 12)
+};
+static_assert(sizeof(Node32) == 32, "Node32 must be 32 bytes");
+constexpr uint32_t N32_KIND_MASK = 0xfu, N32_NO_BBOX = 0x10u, N32_COUNT_SHIFT = 5, N32_COUNT_MASK = 0x7fu, N32_A_SHIFT = 12;
+constexpr uint32_t N32_MAX_COUNT = 127, N32_MAX_A = (1u << 20) - 1u;
 
 // 64 bytes
 struct alignas(64) Sphere {
@@ -76,7 +88,7 @@ constexpr uint32_t INST_TRANSLATE = 1u, INST_ROTATE = 2u;
 struct alignas(16) Medium {
     double neg_inv_density;
     uint32_t phase_material;
-    uint32_t _pad;
+    uint32_t first_node; // first record of the boundary subtree (the second boundary query restarts there)
 };
 
 struct alignas(16) ImageRef {

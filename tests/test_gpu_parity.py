@@ -66,6 +66,39 @@ def test_device_arithmetic_matches_oracle(rt, oracle, gpu):
     assert_bit_equal(rt.debug_eval(rt.RT_DEBUG_RNG_RANGE, kf, df), want_g, "gen_range(-1, 1)")
 
 
+def test_f32_box_test_never_misses_what_the_exact_test_enters(rt, gpu):
+    """The kernel walks f32 boxes with an error-bounded test; it may enter a box the exact f64 test rejects (a wasted
+    visit), never the reverse.  Random and adversarial (grazing, axis-parallel, far-away, tiny-direction) cases."""
+    rng = np.random.default_rng(99)
+    n = 2_000_000
+    scale = 10.0 ** rng.uniform(-2, 3.5, (n, 1))
+    lo = rng.uniform(-1, 1, (n, 3)) * scale
+    hi = lo + rng.uniform(1e-4, 1, (n, 3)) * scale * rng.choice([1e-3, 1.0], (n, 1))
+    o = rng.uniform(-1.5, 1.5, (n, 3)) * scale
+    # aim at a random point of the box (inside, on a face, on an edge, at a corner), then perturb by a few ulps
+    u = rng.choice([0.0, 1.0, 0.5, 0.25], (n, 3), p=[0.3, 0.3, 0.2, 0.2])
+    target = lo + u * (hi - lo)
+    d = target - o
+    d *= 10.0 ** rng.uniform(-3, 3, (n, 1))
+    d[rng.random(n) < 0.05, rng.integers(0, 3)] = 0.0                      # axis-parallel
+    d[rng.random(n) < 0.02] *= 1e-300                                      # 1/d overflows f32
+    o = np.where(rng.random((n, 3)) < 0.1, lo, o)                          # origin exactly on a slab plane
+    d = d * (1.0 + rng.integers(-4, 5, (n, 3)) * 2.0 ** -52)
+    rays = np.concatenate([o, d], axis=1)
+    boxes = np.concatenate([lo, hi], axis=1)
+    for tmin, tmax in ((0.001, np.inf), (0.001, 1.0), (-np.inf, np.inf), (0.5, 0.5000001)):
+        exact, f32 = rt.debug_box_tests(rays, boxes, tmin, tmax)
+        bad = exact & ~f32
+        assert not bad.any(), (tmin, tmax, int(bad.sum()), rays[bad][:3], boxes[bad][:3])
+    # ... and it is not trivially "always enter": on rays that are not aimed at a face, edge or corner it rejects
+    # practically everything the exact test rejects
+    target = lo + rng.uniform(-1.0, 2.0, (n, 3)) * (hi - lo)
+    rays = np.concatenate([o, target - o], axis=1)
+    exact, f32 = rt.debug_box_tests(rays, boxes, 0.001, np.inf)
+    assert not (exact & ~f32).any()
+    assert 0.2 * n < (~exact).sum() and (~f32).sum() > 0.999 * (~exact).sum(), ((~f32).sum(), (~exact).sum())
+
+
 # ---- whole-frame parity, every scene of the reference ---------------------------------------------------
 @pytest.mark.parametrize("name", list(scene_cases.CASES))
 def test_frame_is_bit_identical_to_oracle(rt, oracle, gpu, name):
@@ -166,11 +199,14 @@ def test_counters_match_the_oracle_in_tight_mode(rt, oracle, gpu):
         d = torch.zeros(hs.width * hs.height * 3, dtype=torch.float64, device="cuda")
         got = rt.DeviceScene(hs).render_device_counted(params, d.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert_bit_equal(d.cpu().numpy(), want_img, name)
-        for key in ("samples", "rays", "rng_draws", "sphere_tests", "quad_tests", "medium_visits", "noise_evals",
-                    "image_lookups"):
+        for key in ("samples", "rays", "rng_draws", "noise_evals", "image_lookups"):
             assert got[key] == want[key], (name, key, got[key], want[key])
+        # the conservative f32 box test may enter a box the exact test rejects: never fewer primitive tests than the
+        # exact walk, and only a few per cent more (final_scene: +1.1 % quad tests)
+        for key in ("sphere_tests", "quad_tests", "medium_visits"):
+            assert want[key] <= got[key] <= want[key] * 1.03 + 2, (name, key, got[key], want[key])
         # the kernel tests fewer boxes than the tree has pairs (nested BVH roots and list wrappers are merged)
-        assert 0 < got["node_visits"] <= want["node_visits"], (name, got["node_visits"], want["node_visits"])
+        assert 0 < got["node_visits"] <= want["node_visits"] * 1.03, (name, got["node_visits"], want["node_visits"])
 
 
 def test_errors_are_reported_not_thrown(rt, gpu):

@@ -14,7 +14,7 @@ ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--workload", default="c2")
 ap.add_argument("--bvh", default="reference")
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--grid", default="prim=8,16,24;other=8,16,32;shade=16,24,32,40;box=1,2,4")
+ap.add_argument("--grid", default="prim=8,16;other=16;shade=32,48;box=32,40,48;lds=0,1")
 args = ap.parse_args()
 wl = dict(bench.WORKLOADS[args.workload]); wl.pop("name")
 hs = rt.HostScene(wl["scene"], scene_seed=1, width=wl["width"], aspect=wl["aspect"], spp=args.spp, depth=wl["depth"],
@@ -25,7 +25,7 @@ stream = torch.cuda.current_stream()
 axes = {}
 for part in args.grid.split(";"):
     k, v = part.split("="); axes[k] = [int(x) for x in v.split(",")]
-combos = list(itertools.product(axes["prim"], axes["other"], axes["shade"], axes["box"]))
+combos = list(itertools.product(axes["prim"], axes["other"], axes["shade"], axes["box"], axes.get("lds", [-1])))
 times = {c: [] for c in combos}
 lib = rt.amd_lib()
 params = rt.render_params(seed=1)
@@ -40,5 +40,5 @@ for r in range(args.rounds):
 msamples = hs.width * hs.height * args.spp / 1e6
 rows = sorted(((statistics.median(v), c) for c, v in times.items()))
 for t, c in rows[:12]:
-    print(f"prim={c[0]:3d} other={c[1]:3d} shade={c[2]:3d} box={c[3]:2d}  {t:8.3f} ms  {msamples / t * 1e3:8.1f} Msamples/s")
+    print(f"prim={c[0]:3d} other={c[1]:3d} shade={c[2]:3d} box={c[3]:2d} lds={c[4]:2d}  {t:8.3f} ms  {msamples / t * 1e3:8.1f} Msamples/s")
 print("worst:", rows[-1])
