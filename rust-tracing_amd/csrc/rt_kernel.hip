@@ -931,7 +931,7 @@ struct Workspace {
 // Scheduler knobs (64ths of the live lanes a deferred stage must have queued; box rounds per decision).
 // Defaults were picked on MI355X with bench.py (DESIGN.md "Scheduler"); the RT_* variables are for tuning runs.
 struct Tuning {
-    uint32_t th_prim = 8, th_other = 16, th_shade = 48, th_box = 40;
+    uint32_t th_prim = 8, th_other = 16, th_shade = 32, th_box = 24;
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
@@ -979,7 +979,10 @@ struct rt_scene {
 namespace {
 
 constexpr int GLOBAL_THREADS = 256;             // scene gathered from global memory: 256-thread blocks
-constexpr int LDS_THREADS = 768;                // scene in LDS: one 12-wave workgroup per CU shares the copy
+#ifndef RT_LDS_THREADS
+#define RT_LDS_THREADS 1024 // 16 waves = 4 per SIMD (tools/tune.py: 512 -> 1381, 768 -> 1774, 1024 -> 1921 Msamples/s on C2 at 48 spp)
+#endif
+constexpr int LDS_THREADS = RT_LDS_THREADS;       // scene in LDS: one 12-wave workgroup per CU shares the copy
 constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 
 const void *kernel_for(bool lds, bool counted) {
