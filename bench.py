@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--bvh", default="reference", choices=["reference", "sah"])
     ap.add_argument("--spp", type=int, default=0, help="override spp (smoke runs only: the JSON then names the reduced config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 control flow on ONE GPU (all ranks share device 0, the gather goes "
+                         "through host memory); not a measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,13 +79,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     if rt.amd_lib().rt_device_count() <= local_rank:
         raise SystemExit("bench.py: no HIP device for this rank; the renderer has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     wl_name = wl.pop("name")
@@ -118,7 +127,15 @@ def main():
         if timed:
             ev1.record(stream)
         if world > 1:
-            rtdist.gather_tiles(tiles, gathered, rank, world)
+            if rehearsal:  # host-staged gather (gloo has no device tensors)
+                stream.synchronize()
+                h_tiles = tiles.cpu()
+                h_all = torch.zeros(stride * world, dtype=torch.float64) if rank == 0 else None
+                rtdist.gather_tiles(h_tiles, h_all, rank, world)
+                if rank == 0:
+                    gathered.copy_(h_all)
+            else:
+                rtdist.gather_tiles(tiles, gathered, rank, world)
             if rank == 0:
                 rt.tiles_to_frame_device(w, h, world, gathered.data_ptr(), frame.data_ptr(), stream.cuda_stream)
         return ev0, ev1
@@ -172,7 +189,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name, "scene_seed": SCENE_SEED, "render_seed": RENDER_SEED, "bvh": args.bvh,
                        "width": w, "height": h, "spp": spp, "max_depth": hs.camera.max_depth,
-                       "parallelism": f"tiles{world}" if world > 1 else "single"},
+                       "parallelism": (f"tiles{world}" if world > 1 else "single") + (" [gloo rehearsal on one GPU]" if rehearsal else "")},
             "roofline": {
                 "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic,

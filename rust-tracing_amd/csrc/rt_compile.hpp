@@ -34,13 +34,14 @@ struct CompiledScene {
 
 class Compiler {
   public:
-    explicit Compiler(const rt_scene_desc &d) : d_(d) {}
+    explicit Compiler(const rt_scene_desc &d, bool refit = true) : d_(d), refit_(refit) {}
 
     CompiledScene run() {
         validate_tables();
         emit_object(d_.world, nullptr, -1, false, 0);
         if (out_.nodes.empty()) throw CompileError(RT_ERR_INVALID_ARGUMENT, "scene has no geometry");
         if (out_.nodes.size() > 0x3fffffffu) throw CompileError(RT_ERR_UNSUPPORTED, "too many nodes");
+        if (refit_) refit_range(0, (uint32_t)out_.nodes.size());
         pack_nodes();
         out_.materials.assign(d_.materials, d_.materials + d_.n_materials);
         out_.textures.assign(d_.textures, d_.textures + d_.n_textures);
@@ -65,7 +66,100 @@ class Compiler {
 
   private:
     const rt_scene_desc &d_;
+    bool refit_;
     CompiledScene out_;
+
+    // ---- box refit ------------------------------------------------------------------------------------------
+    // The boxes the reference carries can be much larger than the geometry under them: a HittableList starts from
+    // an all-zero box (derive(Default), src/hittable.rs:50-57), so every Quad::cube list — and every Translate /
+    // RotateY / BVH node above it — also spans the origin (final_scene: 400 such boxes all overlap there).  The
+    // walk only needs boxes that CONTAIN their geometry (a tighter box rejects more rays whose line or interval
+    // cannot reach anything inside, never one that can: DESIGN.md "Box test"), so every record's box is replaced
+    // by the intersection of the reference's box with the bound of the primitives actually below it.
+    struct Bound {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool empty() const { return !(lo[0] <= hi[0]); }
+        void add_point(double x, double y, double z) {
+            const double p[3] = {x, y, z};
+            for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], p[k]); hi[k] = std::fmax(hi[k], p[k]); }
+        }
+        void add(const Bound &b) {
+            if (b.empty()) return;
+            for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], b.lo[k]); hi[k] = std::fmax(hi[k], b.hi[k]); }
+        }
+    };
+    Bound sphere_bound(const Sphere &s) const {
+        Bound b;
+        for (int e = 0; e < 2; ++e) { // both ends of the motion (time in [0, 1), src/sphere.rs:34-46)
+            const double c[3] = {s.center[0] + (e ? s.center_vec[0] : 0.0), s.center[1] + (e ? s.center_vec[1] : 0.0),
+                                 s.center[2] + (e ? s.center_vec[2] : 0.0)};
+            const double r = std::fabs(s.radius);
+            b.add_point(c[0] - r, c[1] - r, c[2] - r);
+            b.add_point(c[0] + r, c[1] + r, c[2] + r);
+            if (!s.is_moving) break;
+        }
+        return b;
+    }
+    Bound quad_bound(const Quad &q) const {
+        Bound b;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                b.add_point(q.q[0] + i * q.u[0] + j * q.v[0], q.q[1] + i * q.u[1] + j * q.v[1], q.q[2] + i * q.u[2] + j * q.v[2]);
+        return b;
+    }
+    // bound of the records [begin, end) (siblings), in the frame they live in
+    Bound refit_range(uint32_t begin, uint32_t end) {
+        Bound all;
+        for (uint32_t k = begin; k < end;) {
+            all.add(refit_node(k));
+            const uint32_t next = out_.nodes[k].skip;
+            k = next > k ? next : k + 1;
+        }
+        return all;
+    }
+    Bound refit_node(uint32_t k) {
+        Node &n = out_.nodes[k];
+        const uint32_t kind = n.kind & NODE_KIND_MASK;
+        Bound b;
+        switch (kind) {
+        case NK_INNER: b = refit_range(k + 1, n.skip); break;
+        case NK_SPHERES: for (uint32_t i = 0; i < n.b; ++i) b.add(sphere_bound(out_.spheres[n.a + i])); break;
+        case NK_QUADS: for (uint32_t i = 0; i < n.b; ++i) b.add(quad_bound(out_.quads[n.a + i])); break;
+        case NK_MEDIUM_ENTER: b = refit_range(k + 1, n.skip - 1); break; // the boundary's geometry
+        case NK_INST_ENTER: {
+            const Bound inner = refit_range(k + 1, n.skip - 1);
+            if (!inner.empty()) { // back to the enclosing frame: rotate the eight corners, then shift (src/hittable.rs:126-149,:88)
+                const Instance &in = out_.instances[n.a];
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        for (int l = 0; l < 2; ++l) {
+                            double x = i ? inner.hi[0] : inner.lo[0], y = j ? inner.hi[1] : inner.lo[1], z = l ? inner.hi[2] : inner.lo[2];
+                            if (in.flags & INST_ROTATE) {
+                                const double nx = in.cos_theta * x + in.sin_theta * z, nz = -in.sin_theta * x + in.cos_theta * z;
+                                x = nx; z = nz;
+                            }
+                            if (in.flags & INST_TRANSLATE) { x += in.offset[0]; y += in.offset[1]; z += in.offset[2]; }
+                            b.add_point(x, y, z);
+                        }
+            }
+            break;
+        }
+        default: break; // NK_INST_EXIT, NK_MEDIUM_EXIT: no geometry of their own
+        }
+        if (!(n.kind & NODE_NO_BBOX) && !b.empty()) {
+            for (int ax = 0; ax < 3; ++ax) {
+                double lo = b.lo[ax], hi = b.hi[ax];
+                // flat on this axis (a quad): give it the thickness the reference's AABB::pad does (src/aabb.rs:35-53)
+                if (hi - lo < 0.0001) { lo -= 0.00005; hi += 0.00005; }
+                // widen by a few ulps: hit points are computed with rounding and may sit a hair outside the exact shape
+                const double slack = 8.0 * 2.220446049250313e-16 * std::fmax(std::fabs(lo), std::fabs(hi));
+                lo -= slack; hi += slack;
+                n.lo[ax] = std::fmax(n.lo[ax], lo);
+                n.hi[ax] = std::fmin(n.hi[ax], hi);
+            }
+        }
+        return b;
+    }
 
     // f64 -> f32 rounded towards -inf / +inf
     static float round_down(double x) {
@@ -346,6 +440,6 @@ class Compiler {
     }
 };
 
-inline CompiledScene compile_scene(const rt_scene_desc &d) { return Compiler(d).run(); }
+inline CompiledScene compile_scene(const rt_scene_desc &d, bool refit = true) { return Compiler(d, refit).run(); }
 
 } // namespace rtd

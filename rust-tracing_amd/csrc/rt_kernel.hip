@@ -933,11 +933,13 @@ struct Workspace {
 struct Tuning {
     uint32_t th_prim = 8, th_other = 16, th_shade = 32, th_box = 24;
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
+    int refit = 1;   // 0: walk the reference's own (looser) boxes
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
         auto env = [](const char *name, uint32_t &v) { if (const char *e = getenv(name)) v = (uint32_t)strtoul(e, nullptr, 10); };
         env("RT_TH_PRIM", th_prim); env("RT_TH_OTHER", th_other); env("RT_TH_SHADE", th_shade); env("RT_TH_BOX", th_box);
         if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
+        if (const char *e = getenv("RT_REFIT")) refit = atoi(e);
         if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
     }
 };
@@ -1194,7 +1196,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     *out_scene = nullptr;
     CompiledScene cs;
     try {
-        cs = compile_scene(*desc);
+        cs = compile_scene(*desc, tuning().refit != 0);
     } catch (const CompileError &e) {
         return fail(e.status, e.what());
     } catch (const std::exception &e) {

@@ -201,10 +201,12 @@ def test_counters_match_the_oracle_in_tight_mode(rt, oracle, gpu):
         assert_bit_equal(d.cpu().numpy(), want_img, name)
         for key in ("samples", "rays", "rng_draws", "noise_evals", "image_lookups"):
             assert got[key] == want[key], (name, key, got[key], want[key])
-        # the conservative f32 box test may enter a box the exact test rejects: never fewer primitive tests than the
-        # exact walk, and only a few per cent more (final_scene: +1.1 % quad tests)
+        # The kernel walks boxes refitted to the geometry (tighter than the reference's, which the oracle walks) with
+        # a conservative f32 test (may enter a box the exact test rejects): it never does more than a few per cent
+        # more primitive work than the oracle's exact walk of the reference's boxes, and usually much less.
         for key in ("sphere_tests", "quad_tests", "medium_visits"):
-            assert want[key] <= got[key] <= want[key] * 1.03 + 2, (name, key, got[key], want[key])
+            assert 0 <= got[key] <= want[key] * 1.03 + 2, (name, key, got[key], want[key])
+        assert got["sphere_tests"] + got["quad_tests"] >= got["rays"] - got["samples"]  # every bounce hit something
         # the kernel tests fewer boxes than the tree has pairs (nested BVH roots and list wrappers are merged)
         assert 0 < got["node_visits"] <= want["node_visits"] * 1.03, (name, got["node_visits"], want["node_visits"])
 
