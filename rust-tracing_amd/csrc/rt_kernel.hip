@@ -241,9 +241,9 @@ struct NodeData {
 // LDS image: node_a[N] = (x.lo, x.hi, y.lo, y.hi) | node_b[N] = (z.lo, z.hi, skip, packed) | spheres (64 B) |
 // quads (144 B).  The two halves of a node record are separate tables so that lanes reading the same half of
 // different records spread over all 16 four-bank slots (a 32-byte record stride would use only 8).
-template <bool LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned char *lds, uint32_t id) {
+template <int LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned char *lds, uint32_t id) {
     float4 a, b;
-    if constexpr (LDS) {
+    if constexpr (LDS != 0) {
         a = reinterpret_cast<const float4 *>(lds)[id];
         b = reinterpret_cast<const float4 *>(lds + P.lds_off_node_b)[id];
     } else {
@@ -310,19 +310,20 @@ RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, dou
     return false;
 }
 
-template <bool COUNT, bool LDS, int THREADS>
+// LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = node, sphere and quad tables in LDS
+template <bool COUNT, int LDS, int THREADS>
 __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    if constexpr (LDS) {
+    if constexpr (LDS != 0) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
         for (uint32_t k = threadIdx.x; k < P.lds_image_bytes / 16u; k += THREADS) dst[k] = P.lds_image[k];
         __syncthreads();
     }
-    const Sphere *const sphere_tab = LDS ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
-    const Quad *const quad_tab = LDS ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
+    const Sphere *const sphere_tab = LDS == 2 ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
+    const Quad *const quad_tab = LDS == 2 ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
     // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree): [6][THREADS]
     double *const lds_world = reinterpret_cast<double *>(lds_raw + P.lds_off_world);
 
@@ -463,31 +464,29 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 if (prim_cur >= prim_end) stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
         } else if (run == ST_QUAD) {
-            // ---------------- Quad::hit (src/quad.rs:96-127), one quad per round ----------------
+            // ---------------- Quad::hit (src/quad.rs:96-127): all quads of the leaf (HittableList order) ----------------
             if (stage == ST_QUAD) {
-                if (COUNT) cn.quad_tests++;
-                const uint32_t q = prim_cur;
-                const Quad *qd = &quad_tab[q];
-                const V3 normal = ld3(qd->normal);
-                const double denom = dot(normal, d);
-                if (!(__builtin_fabs(denom) < 1e-8)) {
+                for (uint32_t q = prim_cur; q < prim_end; ++q) {
+                    if (COUNT) cn.quad_tests++;
+                    const Quad *qd = &quad_tab[q];
+                    const V3 normal = ld3(qd->normal);
+                    const double denom = dot(normal, d);
+                    if (__builtin_fabs(denom) < 1e-8) continue;
                     const double t = (qd->d - dot(normal, o)) / denom;
-                    if (cur_tmin <= t && t <= cur_tmax) {
-                        const V3 intersection = o + d * t;
-                        const V3 php = intersection - ld3(qd->q);
-                        const V3 qw = ld3(qd->w);
-                        const double alpha = dot(qw, cross(php, ld3(qd->v)));
-                        const double beta = dot(qw, cross(ld3(qd->u), php));
-                        if (!(alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0)) {
-                            cur_tmax = t;
-                            tmax32 = (float)t;
-                            if ((mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
-                            else mode |= 0x100u;
-                        }
-                    }
+                    if (!(cur_tmin <= t && t <= cur_tmax)) continue;
+                    const V3 intersection = o + d * t;
+                    const V3 php = intersection - ld3(qd->q);
+                    const V3 qw = ld3(qd->w);
+                    const double alpha = dot(qw, cross(php, ld3(qd->v)));
+                    const double beta = dot(qw, cross(ld3(qd->u), php));
+                    if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
+                    cur_tmax = t;
+                    tmax32 = (float)t;
+                    if ((mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
+                    else mode |= 0x100u;
                 }
-                prim_cur = q + 1;
-                if (prim_cur >= prim_end) stage = node >= n_nodes ? ST_SHADE : ST_BOX;
+                prim_cur = prim_end;
+                stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
         } else if (run == ST_OTHER) {
             // ---------------- frame changes and ConstantMedium steps ----------------
@@ -955,11 +954,12 @@ template <class T> struct DeviceArray {
 struct rt_scene {
     int device = 0;
     int n_cus = 0;
-    int blocks_per_cu[2][2] = {{0, 0}, {0, 0}}; // [scene in LDS?][counted?]
+    int blocks_per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}}; // [LDS level][counted?]
     DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
     uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
     bool has_instances = false;
-    bool lds_fits = false;
+    int lds_level = 0;                          // 0 nothing fits, 1 nodes only, 2 nodes + spheres + quads
+    uint32_t lds_nodes_bytes = 0;               // image prefix that holds the node tables only
     DeviceArray<Node32> nodes;
     DeviceArray<Sphere> spheres;
     DeviceArray<Quad> quads;
@@ -987,14 +987,28 @@ constexpr int GLOBAL_THREADS = 256;             // scene gathered from global me
 constexpr int LDS_THREADS = RT_LDS_THREADS;       // scene in LDS: one 12-wave workgroup per CU shares the copy
 constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 
-const void *kernel_for(bool lds, bool counted) {
-    if (lds) return counted ? (const void *)path_kernel<true, true, LDS_THREADS> : (const void *)path_kernel<false, true, LDS_THREADS>;
-    return counted ? (const void *)path_kernel<true, false, GLOBAL_THREADS> : (const void *)path_kernel<false, false, GLOBAL_THREADS>;
+const void *kernel_for(int lds, bool counted) {
+    if (lds == 2) return counted ? (const void *)path_kernel<true, 2, LDS_THREADS> : (const void *)path_kernel<false, 2, LDS_THREADS>;
+    if (lds == 1) return counted ? (const void *)path_kernel<true, 1, LDS_THREADS> : (const void *)path_kernel<false, 1, LDS_THREADS>;
+    return counted ? (const void *)path_kernel<true, 0, GLOBAL_THREADS> : (const void *)path_kernel<false, 0, GLOBAL_THREADS>;
 }
-size_t dynamic_lds_bytes(const rt_scene *s, bool lds) {
+uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return lds == 2 ? s->lds_image_bytes : lds == 1 ? s->lds_nodes_bytes : 0u; }
+size_t dynamic_lds_bytes(const rt_scene *s, int lds) {
     const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
     const size_t world = (lds && !s->has_instances) ? 0 : (size_t)6 * threads * sizeof(double);
-    return (lds ? s->lds_image_bytes : 0) + world;
+    return lds_image_bytes_for(s, lds) + world;
+}
+template <class... A> void launch_path_kernel(int lds, bool counted, dim3 grid, size_t dyn, hipStream_t stream, const KParams &K) {
+    if (lds == 2) {
+        if (counted) hipLaunchKernelGGL((path_kernel<true, 2, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
+        else hipLaunchKernelGGL((path_kernel<false, 2, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
+    } else if (lds == 1) {
+        if (counted) hipLaunchKernelGGL((path_kernel<true, 1, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
+        else hipLaunchKernelGGL((path_kernel<false, 1, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
+    } else {
+        if (counted) hipLaunchKernelGGL((path_kernel<true, 0, GLOBAL_THREADS>), grid, dim3(GLOBAL_THREADS), dyn, stream, K);
+        else hipLaunchKernelGGL((path_kernel<false, 0, GLOBAL_THREADS>), grid, dim3(GLOBAL_THREADS), dyn, stream, K);
+    }
 }
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
@@ -1073,9 +1087,9 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     if (chunk > n_samples_total) chunk = n_samples_total;
     if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
 
-    const bool lds = scene->lds_fits && tn.use_lds != 0;
+    const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
     const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-    const int bpc = scene->blocks_per_cu[lds ? 1 : 0][counted ? 1 : 0];
+    const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
     const size_t dyn_lds = dynamic_lds_bytes(scene, lds);
     // persistent grid: every resident wave pulls jobs until none are left
     int64_t grid = (int64_t)scene->n_cus * bpc;
@@ -1127,10 +1141,10 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
     K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
     K.n_local_tiles = (uint32_t)n_local;
-    K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds ? scene->lds_image_bytes : 0;
+    K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
-    K.lds_off_world = lds ? scene->lds_image_bytes : 0;
+    K.lds_off_world = lds_image_bytes_for(scene, lds);
     K.th_prim = tn.th_prim; K.th_other = tn.th_other; K.th_shade = tn.th_shade; K.th_box = tn.th_box;
 
     const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
@@ -1141,13 +1155,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
-        if (lds) {
-            if (counted) hipLaunchKernelGGL((path_kernel<true, true, LDS_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
-            else hipLaunchKernelGGL((path_kernel<false, true, LDS_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
-        } else {
-            if (counted) hipLaunchKernelGGL((path_kernel<true, false, GLOBAL_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
-            else hipLaunchKernelGGL((path_kernel<false, false, GLOBAL_THREADS>), dim3((unsigned)grid), dim3(threads), dyn_lds, stream, K);
-        }
+        launch_path_kernel(lds, counted, dim3((unsigned)grid), dyn_lds, stream, K);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(256), 0, stream, K);
         HIP_TRY(hipGetLastError());
@@ -1220,29 +1228,34 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
         const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
         const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
         const size_t world = s->has_instances ? (size_t)6 * LDS_THREADS * sizeof(double) : 0;
-        s->lds_fits = total + world <= LDS_BUDGET_BYTES;
-        if (s->lds_fits) {
-            std::vector<uint4> img(total / 16);
+        s->lds_level = total + world <= LDS_BUDGET_BYTES ? 2 : (off_sph + world <= LDS_BUDGET_BYTES ? 1 : 0);
+        if (s->lds_level) {
+            // level 1 uploads (and copies to LDS) only the node tables, the prefix of the same image
+            const size_t used = s->lds_level == 2 ? total : off_sph;
+            std::vector<uint4> img(used / 16);
             unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
             for (size_t i = 0; i < n; ++i) {
                 memcpy(base + i * 16, &cs.nodes32[i], 16);
                 memcpy(base + off_b + i * 16, reinterpret_cast<const unsigned char *>(&cs.nodes32[i]) + 16, 16);
             }
-            if (!cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
-            if (!cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
+            if (s->lds_level == 2) {
+                if (!cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
+                if (!cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
+            }
             int urc = upload(s->lds_image, img);
             if (urc != RT_OK) { free_scene(s); return urc; }
             s->lds_off_node_b = (uint32_t)off_b;
             s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;
-            s->lds_image_bytes = (uint32_t)total;
+            s->lds_image_bytes = (uint32_t)used;
+            s->lds_nodes_bytes = (uint32_t)off_sph;
         }
     }
-    for (int lds = 0; lds < 2; ++lds)
+    for (int lds = 0; lds < 3; ++lds)
         for (int counted = 0; counted < 2; ++counted) {
-            if (lds && !s->lds_fits) { s->blocks_per_cu[lds][counted] = 0; continue; }
-            const void *fn = kernel_for(lds != 0, counted != 0);
+            if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
+            const void *fn = kernel_for(lds, counted != 0);
             const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-            const size_t dyn = dynamic_lds_bytes(s, lds != 0);
+            const size_t dyn = dynamic_lds_bytes(s, lds);
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             int b = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
@@ -1280,7 +1293,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     st.n_nodes = (uint32_t)cs.nodes.size(); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
     st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
     st.max_instance_depth = cs.max_instance_depth;
-    st.lds_nodes = s->lds_fits ? (uint32_t)cs.nodes.size() : 0; st.lds_bytes = s->lds_fits ? s->lds_image_bytes : 0;
+    st.lds_nodes = s->lds_level ? (uint32_t)cs.nodes.size() : 0; st.lds_bytes = s->lds_level ? s->lds_image_bytes : 0;
     *out_scene = s;
     return RT_OK;
 }
