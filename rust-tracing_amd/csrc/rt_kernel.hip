@@ -310,9 +310,23 @@ RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, dou
     return false;
 }
 
+// What a scene can contain.  A kernel instantiated without a feature has that code compiled out, which matters for
+// more than its size: the register allocation of the whole kernel is set by its hungriest path.
+enum Feature : uint32_t {
+    F_SPHERES = 1u,  // Sphere leaves
+    F_QUADS = 2u,    // Quad leaves
+    F_FRAMES = 4u,   // Translate / RotateY
+    F_MEDIA = 8u,    // ConstantMedium
+    F_TEXTURES = 16u // Checker / Image / Noise textures (without it every texture is a SolidColor)
+};
+constexpr uint32_t F_ALL = 31u;
+
 // LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = node, sphere and quad tables in LDS
-template <bool COUNT, int LDS, int THREADS>
+template <bool COUNT, int LDS, int THREADS, uint32_t FEAT>
 __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
+    constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
+                   HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
+    constexpr bool HAS_OTHER = HAS_FRAMES || HAS_MEDIA;
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,9 +394,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         }
         // ---------------- scheduler: which stage has enough lanes queued? ----------------
         const uint32_t c_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
-        const uint32_t c_sph = (uint32_t)__popcll(__ballot(stage == ST_SPHERE));
-        const uint32_t c_quad = (uint32_t)__popcll(__ballot(stage == ST_QUAD));
-        const uint32_t c_oth = (uint32_t)__popcll(__ballot(stage == ST_OTHER));
+        const uint32_t c_sph = HAS_SPHERES ? (uint32_t)__popcll(__ballot(stage == ST_SPHERE)) : 0u;
+        const uint32_t c_quad = HAS_QUADS ? (uint32_t)__popcll(__ballot(stage == ST_QUAD)) : 0u;
+        const uint32_t c_oth = HAS_OTHER ? (uint32_t)__popcll(__ballot(stage == ST_OTHER)) : 0u;
         const uint32_t c_shade = (uint32_t)__popcll(__ballot(stage == ST_SHADE));
         const uint32_t live = c_box + c_sph + c_quad + c_oth + c_shade;
         if (live == 0) break;
@@ -419,11 +433,11 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         const uint32_t kind = nd.packed & N32_KIND_MASK;
                         if (kind == NK_INNER) {
                             node = node + 1;
-                        } else if (kind == NK_SPHERES || kind == NK_QUADS) {
+                        } else if (!HAS_OTHER || kind == NK_SPHERES || kind == NK_QUADS) {
                             prim_cur = nd.packed >> N32_A_SHIFT;
                             prim_end = prim_cur + ((nd.packed >> N32_COUNT_SHIFT) & N32_COUNT_MASK);
                             node = nd.skip; // where the walk continues after the leaf's primitives
-                            stage = kind == NK_SPHERES ? ST_SPHERE : ST_QUAD;
+                            stage = (HAS_SPHERES && (!HAS_QUADS || kind == NK_SPHERES)) ? ST_SPHERE : ST_QUAD;
                         } else {
                             stage = ST_OTHER;
                         }
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 in_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
                 if (COUNT && in_box * 64u >= P.th_box * live && in_box > 0) { prof_rounds[ST_BOX] += 1; prof_lanes[ST_BOX] += in_box; }
             } while (in_box * 64u >= P.th_box * live && in_box > 0);
-        } else if (run == ST_SPHERE) {
+        } else if (HAS_SPHERES && run == ST_SPHERE) {
             // ---------------- Sphere::hit (src/sphere.rs:58-83), one sphere per round ----------------
             if (stage == ST_SPHERE) {
                 if (COUNT) cn.sphere_tests++;
@@ -456,14 +470,14 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (ok) {
                         cur_tmax = root;
                         tmax32 = (float)root;
-                        if ((mode & 3u) == 0) { best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
+                        if (!HAS_MEDIA || (mode & 3u) == 0) { best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
                         else mode |= 0x100u;
                     }
                 }
                 prim_cur = q + 1;
                 if (prim_cur >= prim_end) stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
-        } else if (run == ST_QUAD) {
+        } else if (HAS_QUADS && run == ST_QUAD) {
             // ---------------- Quad::hit (src/quad.rs:96-127): all quads of the leaf (HittableList order) ----------------
             if (stage == ST_QUAD) {
                 for (uint32_t q = prim_cur; q < prim_end; ++q) {
@@ -482,19 +496,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
                     cur_tmax = t;
                     tmax32 = (float)t;
-                    if ((mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
+                    if (!HAS_MEDIA || (mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
                     else mode |= 0x100u;
                 }
                 prim_cur = prim_end;
                 stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
-        } else if (run == ST_OTHER) {
+        } else if (HAS_OTHER && run == ST_OTHER) {
             // ---------------- frame changes and ConstantMedium steps ----------------
             if (stage == ST_OTHER) {
                 const NodeData nd = load_node<LDS>(P, lds_raw, node);
                 const uint32_t kind = nd.packed & N32_KIND_MASK;
                 const uint32_t na = nd.packed >> N32_A_SHIFT;
-                if (kind == NK_INST_ENTER) {
+                if (HAS_FRAMES && kind == NK_INST_ENTER) {
                     if (COUNT) cn.instance_enters++;
                     if (cur_inst < 0) { // leaving the world frame: park the world ray
                         lds_world[0 * THREADS + threadIdx.x] = o.x; lds_world[1 * THREADS + threadIdx.x] = o.y; lds_world[2 * THREADS + threadIdx.x] = o.z;
@@ -503,19 +517,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     apply_instance(P.insts[na], o, d);
                     cur_inst = (int32_t)na;
                     node = node + 1;
-                } else if (kind == NK_INST_EXIT) {
+                } else if (HAS_FRAMES && kind == NK_INST_EXIT) {
                     cur_inst = P.insts[na].parent;
                     o = v3(lds_world[0 * THREADS + threadIdx.x], lds_world[1 * THREADS + threadIdx.x], lds_world[2 * THREADS + threadIdx.x]);
                     d = v3(lds_world[3 * THREADS + threadIdx.x], lds_world[4 * THREADS + threadIdx.x], lds_world[5 * THREADS + threadIdx.x]);
                     ray_to_frame(P.insts, cur_inst, o, d);
                     node = node + 1;
-                } else if (kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
+                } else if (HAS_MEDIA && kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
                     if (COUNT) cn.medium_visits++;
                     mode = 1;
                     cur_tmin = -INF;
                     cur_tmax = INF;
                     node = node + 1;
-                } else { // NK_MEDIUM_EXIT
+                } else if (HAS_MEDIA) { // NK_MEDIUM_EXIT
                     bool again = false;
                     const bool sub_hit = (mode & 0x100u) != 0;
                     if ((mode & 3u) == 1) {
@@ -575,25 +589,25 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 } else {
                     // rebuild the HitRecord in its own frame, then carry it to the world
                     V3 lo = o, ld = d; // all frames are closed at this point: (o, d) is the world ray
-                    ray_to_frame(P.insts, best_inst, lo, ld);
+                    if (HAS_FRAMES) ray_to_frame(P.insts, best_inst, lo, ld);
                     V3 p = lo + ld * best_t; // Ray::at (src/ray.rs:30-32)
                     V3 outward_normal;
                     uint32_t mat;
                     double u = 0.0, v = 0.0;
                     const uint32_t pk = best_prim & PRIM_KIND_MASK, pi = best_prim & PRIM_INDEX_MASK;
                     bool uv_from_sphere = false;
-                    if (pk == PRIM_SPHERE) { // src/sphere.rs:85-88
+                    if (HAS_SPHERES && (pk == PRIM_SPHERE || (!HAS_QUADS && !HAS_MEDIA))) { // src/sphere.rs:85-88
                         const Sphere *s = &sphere_tab[pi];
                         V3 center = ld3(s->center);
                         if (s->is_moving) center = center + ld3(s->center_vec) * time;
                         outward_normal = div(p - center, s->radius);
                         mat = s->material;
                         uv_from_sphere = true;
-                    } else if (pk == PRIM_QUAD) { // src/quad.rs:118-132
+                    } else if (HAS_QUADS && (pk == PRIM_QUAD || !HAS_MEDIA)) { // src/quad.rs:118-132
                         const Quad *qd = &quad_tab[pi];
                         outward_normal = ld3(qd->normal);
                         mat = qd->material;
-                        if (P.mats[mat].needs_uv) {
+                        if (HAS_TEXTURES && P.mats[mat].needs_uv) {
                             const V3 php = p - ld3(qd->q);
                             const V3 qw = ld3(qd->w);
                             u = dot(qw, cross(php, ld3(qd->v)));
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         mat = P.media[pi].phase_material;
                     }
                     const DMaterial *m = &P.mats[mat];
-                    if (uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
+                    if (HAS_TEXTURES && uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
                         const double PI = 3.14159265358979323846264338327950288;
                         const double theta = rt_acos(-outward_normal.y);
                         const double phi = rt_atan2(-outward_normal.z, outward_normal.x) + PI;
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // HitRecord::new (src/hittable.rs:22-37)
                     const bool front_face = dot(ld, outward_normal) < 0.0;
                     V3 normal = front_face ? outward_normal : -outward_normal;
-                    hit_to_world(P.insts, best_inst, p, normal);
+                    if (HAS_FRAMES) hit_to_world(P.insts, best_inst, p, normal);
 
                     const uint32_t mk = m->kind;
                     // Every material that reads a texture reads exactly one, after its random draws (textures draw
@@ -623,7 +637,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     V3 tex = v3(1.0, 1.0, 1.0);
                     V3 rs = v3(0.0, 0.0, 0.0);
                     if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
-                    if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) tex = texture_value<COUNT>(P, m->texture, u, v, p, cn);
+                    if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) {
+                        if constexpr (HAS_TEXTURES) tex = texture_value<COUNT>(P, m->texture, u, v, p, cn);
+                        else tex = from(P.texs[m->texture].color); // every texture is a SolidColor (src/texture.rs:32-36)
+                    }
                     V3 attenuation = tex;
                     bool unit_attenuation = false;
                     V3 new_dir = normal;
@@ -959,6 +976,7 @@ struct rt_scene {
     uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
     bool has_instances = false;
     int lds_level = 0;                          // 0 nothing fits, 1 nodes only, 2 nodes + spheres + quads
+    uint32_t features = F_ALL;                  // Feature bits the scene uses
     uint32_t lds_nodes_bytes = 0;               // image prefix that holds the node tables only
     DeviceArray<Node32> nodes;
     DeviceArray<Sphere> spheres;
@@ -987,28 +1005,31 @@ constexpr int GLOBAL_THREADS = 256;             // scene gathered from global me
 constexpr int LDS_THREADS = RT_LDS_THREADS;       // scene in LDS: one 12-wave workgroup per CU shares the copy
 constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 
-const void *kernel_for(int lds, bool counted) {
-    if (lds == 2) return counted ? (const void *)path_kernel<true, 2, LDS_THREADS> : (const void *)path_kernel<false, 2, LDS_THREADS>;
-    if (lds == 1) return counted ? (const void *)path_kernel<true, 1, LDS_THREADS> : (const void *)path_kernel<false, 1, LDS_THREADS>;
-    return counted ? (const void *)path_kernel<true, 0, GLOBAL_THREADS> : (const void *)path_kernel<false, 0, GLOBAL_THREADS>;
+// The kernel instantiations that exist: the general one (every feature) at each LDS level, plus two specialised
+// ones for scenes that fit the LDS entirely and use a subset of the features (BASELINE configs 1/2 and 3).
+constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
+constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
+uint32_t kernel_features_for(uint32_t scene_features, int lds) {
+    if (lds == 2 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
+    if (lds == 2 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
+    return F_ALL;
+}
+const void *kernel_for(int lds, bool counted, uint32_t feat) {
+#define RT_PICK(L, T, F) (counted ? (const void *)path_kernel<true, L, T, F> : (const void *)path_kernel<false, L, T, F>)
+    if (lds == 2) {
+        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(2, LDS_THREADS, FEAT_SPHERES_SOLID);
+        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(2, LDS_THREADS, FEAT_QUADS_FRAMES);
+        return RT_PICK(2, LDS_THREADS, F_ALL);
+    }
+    if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL);
+    return RT_PICK(0, GLOBAL_THREADS, F_ALL);
+#undef RT_PICK
 }
 uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return lds == 2 ? s->lds_image_bytes : lds == 1 ? s->lds_nodes_bytes : 0u; }
 size_t dynamic_lds_bytes(const rt_scene *s, int lds) {
     const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
     const size_t world = (lds && !s->has_instances) ? 0 : (size_t)6 * threads * sizeof(double);
     return lds_image_bytes_for(s, lds) + world;
-}
-template <class... A> void launch_path_kernel(int lds, bool counted, dim3 grid, size_t dyn, hipStream_t stream, const KParams &K) {
-    if (lds == 2) {
-        if (counted) hipLaunchKernelGGL((path_kernel<true, 2, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
-        else hipLaunchKernelGGL((path_kernel<false, 2, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
-    } else if (lds == 1) {
-        if (counted) hipLaunchKernelGGL((path_kernel<true, 1, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
-        else hipLaunchKernelGGL((path_kernel<false, 1, LDS_THREADS>), grid, dim3(LDS_THREADS), dyn, stream, K);
-    } else {
-        if (counted) hipLaunchKernelGGL((path_kernel<true, 0, GLOBAL_THREADS>), grid, dim3(GLOBAL_THREADS), dyn, stream, K);
-        else hipLaunchKernelGGL((path_kernel<false, 0, GLOBAL_THREADS>), grid, dim3(GLOBAL_THREADS), dyn, stream, K);
-    }
 }
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
@@ -1155,7 +1176,10 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
-        launch_path_kernel(lds, counted, dim3((unsigned)grid), dyn_lds, stream, K);
+        {
+            void *args[] = {(void *)&K};
+            HIP_TRY(hipLaunchKernel(kernel_for(lds, counted, kernel_features_for(scene->features, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
+        }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(256), 0, stream, K);
         HIP_TRY(hipGetLastError());
@@ -1221,6 +1245,10 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "hipGetDeviceProperties failed"); }
     s->n_cus = prop.multiProcessorCount;
     s->has_instances = !cs.instances.empty();
+    s->features = (cs.spheres.empty() ? 0u : F_SPHERES) | (cs.quads.empty() ? 0u : F_QUADS) | (cs.instances.empty() ? 0u : F_FRAMES) |
+                  (cs.media.empty() ? 0u : F_MEDIA);
+    for (const auto &t : cs.textures)
+        if (t.kind != RT_TEXTURE_SOLID) s->features |= F_TEXTURES;
     // LDS image (see load_node): the two halves of the node records as separate tables, then spheres and quads
     {
         const size_t n = cs.nodes32.size();
@@ -1253,7 +1281,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     for (int lds = 0; lds < 3; ++lds)
         for (int counted = 0; counted < 2; ++counted) {
             if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
-            const void *fn = kernel_for(lds, counted != 0);
+            const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds));
             const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
             const size_t dyn = dynamic_lds_bytes(s, lds);
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
