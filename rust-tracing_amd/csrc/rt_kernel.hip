@@ -258,8 +258,8 @@ template <int LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned ch
     return n;
 }
 
-// f32 copies of a ray for the conservative box test: origin, 1/d, and the bound E on how far rounding the origin
-// to f32 can move a slab distance; `degenerate`: some 1/d or E is not finite -> every box is entered.
+// f32 copies of a ray for the conservative box test: origin, 1/d, and a bound E on how far rounding the origin to
+// f32 can move a slab distance on each axis; `degenerate`: some 1/d or E is not finite -> every box is entered.
 struct Ray32 {
     float ox, oy, oz, ix, iy, iz, ex, ey, ez;
     bool degenerate;
@@ -267,8 +267,9 @@ struct Ray32 {
 RT_DEV Ray32 make_ray32(V3 o, V3 d) {
     Ray32 r;
     r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
-    // 1/d is the reference's per-visit quotient (src/aabb.rs:66), rounded once more to f32
-    r.ix = (float)(1.0 / d.x); r.iy = (float)(1.0 / d.y); r.iz = (float)(1.0 / d.z);
+    // 1/d (the reference's per-visit quotient, src/aabb.rs:66) to f32 accuracy: v_rcp_f32 of the rounded d is within
+    // 2 ulp of it, which the test's slack absorbs (below)
+    r.ix = __builtin_amdgcn_rcpf((float)d.x); r.iy = __builtin_amdgcn_rcpf((float)d.y); r.iz = __builtin_amdgcn_rcpf((float)d.z);
     // |o - o32| <= 2^-24 |o|, i.e. at most 2^-24 |o| |1/d| in t; E carries a 4x margin
     r.ex = __builtin_fabsf(r.ox * r.ix) * 0x1p-22f;
     r.ey = __builtin_fabsf(r.oy * r.iy) * 0x1p-22f;
@@ -279,22 +280,24 @@ RT_DEV Ray32 make_ray32(V3 o, V3 d) {
 }
 // Conservative f32 slab test.  The exact test (f64, interval narrowed axis by axis; equivalent to the reference's
 // un-narrowed one, DESIGN.md "Box test") passes iff max(near) < min(far) over the three slabs and (tmin, tmax).
-// Here: boxes are rounded outward, E bounds the effect of rounding the origin, and the final interval is widened by
-// 2^-21 relative (> the three roundings of 2^-24 in (b - o) * (1/d) plus the conversions of 1/d, tmin and tmax).
-// So this test passes whenever the exact one does; when it passes although the exact one would not, the visit
-// finds nothing (primitives are intersected in f64).  A record without a box carries (-inf, +inf): always passes.
+// Here: boxes are rounded outward; E bounds the effect of rounding the origin; every computed slab distance
+// (b - o) * (1/d) carries at most 2^-24 (subtraction) + 2^-24 (product) + 2^-22 (1/d: conversion of d, v_rcp_f32)
+// relative error, and tmin / tmax 2^-24 from their conversion: under 2^-21.5 in all.  Each slab's near / far distance
+// is moved outward by its E, and the test declares a miss only if enter still exceeds leave by more than
+// 2^-20 (|enter| + |leave|) — so it passes whenever the exact one does;
+// when it passes although the exact one would not, the visit finds nothing (primitives are intersected in f64).
+// A record without a box carries (-inf, +inf): always passes (inf - inf = NaN compares false).
 RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, float tmin32, float tmax32) {
     const float t0x = (lo[0] - r.ox) * r.ix, t1x = (hi[0] - r.ox) * r.ix;
     const float t0y = (lo[1] - r.oy) * r.iy, t1y = (hi[1] - r.oy) * r.iy;
     const float t0z = (lo[2] - r.oz) * r.iz, t1z = (hi[2] - r.oz) * r.iz;
-    const float nx = __builtin_fminf(t0x, t1x) - r.ex, fx = __builtin_fmaxf(t0x, t1x) + r.ex;
-    const float ny = __builtin_fminf(t0y, t1y) - r.ey, fy = __builtin_fmaxf(t0y, t1y) + r.ey;
-    const float nz = __builtin_fminf(t0z, t1z) - r.ez, fz = __builtin_fmaxf(t0z, t1z) + r.ez;
-    const float enter = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin32));
-    const float leave = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tmax32));
-    const float lb = enter - __builtin_fabsf(enter) * 0x1p-21f;
-    const float ub = leave + __builtin_fabsf(leave) * 0x1p-21f;
-    return !r.degenerate && lb > ub; // a NaN compares false: pass
+    const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x) - r.ex, __builtin_fminf(t0y, t1y) - r.ey),
+                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z) - r.ez, tmin32));
+    const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x) + r.ex, __builtin_fmaxf(t0y, t1y) + r.ey),
+                                        __builtin_fminf(__builtin_fmaxf(t0z, t1z) + r.ez, tmax32));
+    const float gap = enter - leave;
+    const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
+    return !r.degenerate && gap > tol; // a NaN compares false: pass
 }
 // The exact f64 test the kernel used before (and the oracle's tight mode): kept as the yardstick for the test hook
 RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, double tmin, double tmax) {
@@ -427,21 +430,20 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const NodeData nd = load_node<LDS>(P, lds_raw, node);
                     if (COUNT) cn.node_visits += (nd.packed & N32_NO_BBOX) ? 0u : 1u;
                     const bool miss = box_miss_f32(nd.lo, nd.hi, r32, tmin32, tmax32);
-                    if (miss) {
-                        node = nd.skip;
-                    } else {
-                        const uint32_t kind = nd.packed & N32_KIND_MASK;
-                        if (kind == NK_INNER) {
-                            node = node + 1;
-                        } else if (!HAS_OTHER || kind == NK_SPHERES || kind == NK_QUADS) {
-                            prim_cur = nd.packed >> N32_A_SHIFT;
-                            prim_end = prim_cur + ((nd.packed >> N32_COUNT_SHIFT) & N32_COUNT_MASK);
-                            node = nd.skip; // where the walk continues after the leaf's primitives
-                            stage = (HAS_SPHERES && (!HAS_QUADS || kind == NK_SPHERES)) ? ST_SPHERE : ST_QUAD;
-                        } else {
-                            stage = ST_OTHER;
-                        }
+                    // dispatch on the record kind, branch-free: INNER (0) walks on to the next record, a leaf (1, 2)
+                    // queues for its primitive stage and will continue at `skip`, anything else (>= 3) queues for ST_OTHER
+                    const uint32_t kind = nd.packed & N32_KIND_MASK;
+                    const uint32_t a_field = nd.packed >> N32_A_SHIFT;
+                    const bool is_leaf = kind == NK_SPHERES || kind == NK_QUADS;
+                    if (!miss && is_leaf) {
+                        prim_cur = a_field;
+                        prim_end = a_field + ((nd.packed >> N32_COUNT_SHIFT) & N32_COUNT_MASK);
                     }
+                    // NodeKind INNER / SPHERES / QUADS = 0 / 1 / 2 = Stage ST_BOX / ST_SPHERE / ST_QUAD
+                    const uint32_t hit_stage = (!HAS_OTHER || kind < 3u) ? kind : (uint32_t)ST_OTHER;
+                    const uint32_t hit_node = kind == NK_INNER ? node + 1u : (is_leaf ? nd.skip : node);
+                    node = miss ? nd.skip : hit_node;
+                    stage = miss ? (uint32_t)ST_BOX : hit_stage;
                     if (stage == ST_BOX && node >= n_nodes) stage = ST_SHADE;
                 }
                 in_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));

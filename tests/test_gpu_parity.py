@@ -96,7 +96,7 @@ def test_f32_box_test_never_misses_what_the_exact_test_enters(rt, gpu):
     rays = np.concatenate([o, target - o], axis=1)
     exact, f32 = rt.debug_box_tests(rays, boxes, 0.001, np.inf)
     assert not (exact & ~f32).any()
-    assert 0.2 * n < (~exact).sum() and (~f32).sum() > 0.999 * (~exact).sum(), ((~f32).sum(), (~exact).sum())
+    assert 0.2 * n < (~exact).sum() and (~f32).sum() > 0.99 * (~exact).sum(), ((~f32).sum(), (~exact).sum())
 
 
 # ---- whole-frame parity, every scene of the reference ---------------------------------------------------
