@@ -164,3 +164,45 @@ def test_image_ingest(rt, tmp_path):
     assert b"cannot open" in lib.rth_last_error()
     with pytest.raises(rt.RtError):
         rt.HostScene(2, earth_image="/nonexistent.jpg")
+
+
+def test_jpeg_decoder_matches_pillow(rt, tmp_path):
+    """ImageTexture ingest (reference: image::io::Reader::open(path).decode(), src/texture.rs:78).  The decoder follows
+    libjpeg's arithmetic (islow IDCT, fancy chroma upsampling, fixed-point colour conversion), so it must agree with
+    Pillow's libjpeg decode of the same file — exactly, on every sampling mode."""
+    from PIL import Image
+    lib = rt.host_lib()
+    rng = np.random.default_rng(0)
+    H, W = 123, 211                                     # not a multiple of any MCU size
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([128 + 100 * np.sin(xx / 17.0) * np.cos(yy / 11.0), 128 + 90 * np.cos(xx / 23.0 + yy / 19.0),
+                    (xx * 3 + yy * 5) % 256], -1)
+    img = np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+    cases = {"444": dict(subsampling=0, quality=92), "420": dict(subsampling=2, quality=85),
+             "422": dict(subsampling=1, quality=60), "420_restart": dict(subsampling=2, quality=85, restart_marker_rows=1),
+             "gray": dict(quality=80), "tiny": dict(subsampling=2, quality=90)}
+    for name, kw in cases.items():
+        path = tmp_path / f"{name}.jpg"
+        src = img[:, :, 0] if name == "gray" else (img[:5, :3] if name == "tiny" else img)
+        try:
+            Image.fromarray(src).save(path, "JPEG", **kw)
+        except TypeError:                               # older Pillow: no restart_marker_rows
+            kw.pop("restart_marker_rows", None)
+            Image.fromarray(src).save(path, "JPEG", **kw)
+        want = np.asarray(Image.open(path).convert("RGB"))
+        w, h = C.c_int32(), C.c_int32()
+        assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0) == 0, lib.rth_last_error()
+        got = np.zeros(w.value * h.value * 3, dtype=np.uint8)
+        assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), got.ctypes.data_as(C.POINTER(C.c_uint8)), got.size) == 0
+        assert (h.value, w.value) == want.shape[:2], name
+        assert np.array_equal(got.reshape(want.shape), want), name
+    # progressive files are refused with a message, not mis-decoded
+    path = tmp_path / "prog.jpg"
+    Image.fromarray(img).save(path, "JPEG", progressive=True)
+    w, h = C.c_int32(), C.c_int32()
+    assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0) != 0
+    assert b"progressive" in lib.rth_last_error()
+    # and a texture built from a JPEG reaches the scene description
+    Image.fromarray(img).save(tmp_path / "earth.jpg", "JPEG", quality=90)
+    hs = rt.HostScene(2, spp=1, earth_image=str(tmp_path / "earth.jpg"))
+    assert (hs.desc.images[0].width, hs.desc.images[0].height) == (W, H)
