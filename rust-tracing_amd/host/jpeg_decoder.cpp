@@ -301,6 +301,13 @@ struct Decoder {
         }
         const int dw = c.width;
         std::vector<uint8_t> line((size_t)dw * 2 + 2);
+        if (dw <= 2 || hs == 1) { // IJG uses the triangle filter only when the component is more than 2 samples wide
+            for (int y = 0; y < height; ++y) {
+                const uint8_t *in = row(vs == 2 ? y / 2 : y);
+                for (int x = 0; x < width; ++x) out[(size_t)y * width + x] = in[hs == 2 ? x / 2 : x];
+            }
+            return out;
+        }
         for (int y = 0; y < height; ++y) {
             const int iy = vs == 2 ? y / 2 : y;
             const uint8_t *in0 = row(iy);
