@@ -126,6 +126,7 @@ class Compiler {
         case NK_SPHERES: for (uint32_t i = 0; i < n.b; ++i) b.add(sphere_bound(out_.spheres[n.a + i])); break;
         case NK_QUADS: for (uint32_t i = 0; i < n.b; ++i) b.add(quad_bound(out_.quads[n.a + i])); break;
         case NK_MEDIUM_ENTER: b = refit_range(k + 1, n.skip - 1); break; // the boundary's geometry
+        case NK_MEDIUM_SPHERE: b = sphere_bound(out_.spheres[out_.media[n.a].first_node]); break;
         case NK_INST_ENTER: {
             const Bound inner = refit_range(k + 1, n.skip - 1);
             if (!inner.empty()) { // back to the enclosing frame: rotate the eight corners, then shift (src/hittable.rs:126-149,:88)
@@ -406,6 +407,12 @@ class Compiler {
             dm.phase_material = (uint32_t)m.phase_material;
             out_.media.push_back(dm);
             const uint32_t id = (uint32_t)out_.media.size() - 1u;
+            if (m.boundary.kind == RT_HITTABLE_SPHERE) {
+                // boundary.hit() twice on one sphere (src/constant_medium.rs:35-38) needs no walk: one record
+                out_.media[id].first_node = add_sphere(m.boundary.index);
+                close(push_node(NK_MEDIUM_SPHERE, bbox, id, 0));
+                break;
+            }
             uint32_t enter = push_node(NK_MEDIUM_ENTER, bbox, id, 0);
             const uint32_t first_child = (uint32_t)out_.nodes.size();
             out_.media[id].first_node = first_child;

@@ -531,6 +531,49 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     cur_tmin = -INF;
                     cur_tmax = INF;
                     node = node + 1;
+                } else if (HAS_MEDIA && kind == NK_MEDIUM_SPHERE) {
+                    // ConstantMedium::hit with a Sphere boundary (src/constant_medium.rs:33-71): the two boundary.hit calls
+                    // solve the same quadratic (src/sphere.rs:58-83), first over (-inf, inf), then over (t1 + 0.0001, inf)
+                    if (COUNT) { cn.medium_visits++; cn.sphere_tests++; }
+                    const Medium md = P.media[na];
+                    const Sphere *s = &P.spheres[md.first_node];
+                    V3 center = ld3(s->center);
+                    if (s->is_moving) center = center + ld3(s->center_vec) * time;
+                    const V3 oc = o - center;
+                    const double half_b = dot(oc, d);
+                    const double c = len2(oc) - s->radius * s->radius;
+                    const double discriminant = half_b * half_b - a * c;
+                    if (!(discriminant < 0.0)) {
+                        const double sqrtd = __builtin_sqrt(discriminant);
+                        const double root_a = (-half_b - sqrtd) / a, root_b = (-half_b + sqrtd) / a;
+                        // Interval::surrounds is strict at both ends (src/interval.rs:44-46)
+                        const bool a1 = -INF < root_a && root_a < INF, b1 = -INF < root_b && root_b < INF;
+                        if (a1 || b1) {
+                            const double t1 = a1 ? root_a : root_b;
+                            if (COUNT) cn.sphere_tests++;
+                            const double lo2 = t1 + 0.0001;
+                            const bool a2 = lo2 < root_a && root_a < INF, b2 = lo2 < root_b && root_b < INF;
+                            if (a2 || b2) {
+                                const double t2 = a2 ? root_a : root_b;
+                                double h1 = __builtin_fmax(t1, 0.001);
+                                const double h2 = __builtin_fmin(t2, best_t);
+                                if (h1 < h2) {
+                                    h1 = __builtin_fmax(h1, 0.0);
+                                    const double ray_length = __builtin_sqrt(len2(d));
+                                    const double distance_inside_boundary = (h2 - h1) * ray_length;
+                                    if (COUNT) cn.rng_draws++;
+                                    const double hit_distance = md.neg_inv_density * rt_log(rng.random());
+                                    if (hit_distance <= distance_inside_boundary) {
+                                        best_t = h1 + hit_distance / ray_length;
+                                        best_prim = PRIM_MEDIUM | na;
+                                        best_inst = cur_inst;
+                                        cur_tmax = best_t;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    node = nd.skip;
                 } else if (HAS_MEDIA) { // NK_MEDIUM_EXIT
                     bool again = false;
                     const bool sub_hit = (mode & 0x100u) != 0;

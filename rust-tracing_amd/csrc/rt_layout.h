@@ -21,6 +21,7 @@ enum NodeKind : uint32_t {
     NK_INST_EXIT = 4,    // a = instance index
     NK_MEDIUM_ENTER = 5, // a = medium index
     NK_MEDIUM_EXIT = 6,  // a = medium index, b = first record of the boundary subtree
+    NK_MEDIUM_SPHERE = 7, // a = medium index; the boundary is one Sphere: both boundary queries are solved in place
 };
 constexpr uint32_t NODE_KIND_MASK = 0xffu;
 constexpr uint32_t NODE_NO_BBOX = 0x100u; // the reference performs no box test here (object inside a list /
@@ -88,7 +89,8 @@ constexpr uint32_t INST_TRANSLATE = 1u, INST_ROTATE = 2u;
 struct alignas(16) Medium {
     double neg_inv_density;
     uint32_t phase_material;
-    uint32_t first_node; // first record of the boundary subtree (the second boundary query restarts there)
+    uint32_t first_node; // first record of the boundary subtree (the second boundary query restarts there);
+                         // for NK_MEDIUM_SPHERE: index of the boundary sphere
 };
 
 struct alignas(16) ImageRef {
