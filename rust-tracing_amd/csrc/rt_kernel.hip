@@ -78,7 +78,7 @@ struct KParams {
     const uint4 *lds_image;
     uint32_t lds_image_bytes;
     uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
-    uint32_t lds_off_world;         // per-thread world-ray slots: [6][blockDim.x] doubles
+    double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
 };
 
 struct Counts {
@@ -324,7 +324,7 @@ enum Feature : uint32_t {
 };
 constexpr uint32_t F_ALL = 31u;
 
-// LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = node, sphere and quad tables in LDS
+// LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = + sphere table; 3 = + quad table
 template <bool COUNT, int LDS, int THREADS, uint32_t FEAT>
 __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
@@ -339,10 +339,11 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         for (uint32_t k = threadIdx.x; k < P.lds_image_bytes / 16u; k += THREADS) dst[k] = P.lds_image[k];
         __syncthreads();
     }
-    const Sphere *const sphere_tab = LDS == 2 ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
-    const Quad *const quad_tab = LDS == 2 ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
-    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree): [6][THREADS]
-    double *const lds_world = reinterpret_cast<double *>(lds_raw + P.lds_off_world);
+    const Sphere *const sphere_tab = LDS >= 2 ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
+    const Quad *const quad_tab = LDS == 3 ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
+    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree) is parked in global
+    // memory (touched 0.3-2.6 times per sample; the LDS is worth more as scene storage)
+    double *const world_slot = P.world_slots + gtid;
 
     Counts cn{};
     Rng rng;
@@ -513,16 +514,18 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 if (HAS_FRAMES && kind == NK_INST_ENTER) {
                     if (COUNT) cn.instance_enters++;
                     if (cur_inst < 0) { // leaving the world frame: park the world ray
-                        lds_world[0 * THREADS + threadIdx.x] = o.x; lds_world[1 * THREADS + threadIdx.x] = o.y; lds_world[2 * THREADS + threadIdx.x] = o.z;
-                        lds_world[3 * THREADS + threadIdx.x] = d.x; lds_world[4 * THREADS + threadIdx.x] = d.y; lds_world[5 * THREADS + threadIdx.x] = d.z;
+                        const size_t ws = P.n_threads;
+                        world_slot[0] = o.x; world_slot[ws] = o.y; world_slot[2 * ws] = o.z;
+                        world_slot[3 * ws] = d.x; world_slot[4 * ws] = d.y; world_slot[5 * ws] = d.z;
                     }
                     apply_instance(P.insts[na], o, d);
                     cur_inst = (int32_t)na;
                     node = node + 1;
                 } else if (HAS_FRAMES && kind == NK_INST_EXIT) {
                     cur_inst = P.insts[na].parent;
-                    o = v3(lds_world[0 * THREADS + threadIdx.x], lds_world[1 * THREADS + threadIdx.x], lds_world[2 * THREADS + threadIdx.x]);
-                    d = v3(lds_world[3 * THREADS + threadIdx.x], lds_world[4 * THREADS + threadIdx.x], lds_world[5 * THREADS + threadIdx.x]);
+                    const size_t ws = P.n_threads;
+                    o = v3(world_slot[0], world_slot[ws], world_slot[2 * ws]);
+                    d = v3(world_slot[3 * ws], world_slot[4 * ws], world_slot[5 * ws]);
                     ray_to_frame(P.insts, cur_inst, o, d);
                     node = node + 1;
                 } else if (HAS_MEDIA && kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // solve the same quadratic (src/sphere.rs:58-83), first over (-inf, inf), then over (t1 + 0.0001, inf)
                     if (COUNT) { cn.medium_visits++; cn.sphere_tests++; }
                     const Medium md = P.media[na];
-                    const Sphere *s = &P.spheres[md.first_node];
+                    const Sphere *s = &sphere_tab[md.first_node];
                     V3 center = ld3(s->center);
                     if (s->is_moving) center = center + ld3(s->center_vec) * time;
                     const V3 oc = o - center;
@@ -983,6 +986,8 @@ int fail(int status, const std::string &msg) {
 struct Workspace {
     double *att_stack = nullptr;
     size_t att_bytes = 0;
+    double *world_slots = nullptr; // [6][n_threads]
+    size_t world_bytes = 0;
     double *samples = nullptr; // sample buffer of one launch
     size_t sample_bytes = 0;
     uint32_t *job_counter = nullptr;
@@ -1016,13 +1021,13 @@ template <class T> struct DeviceArray {
 struct rt_scene {
     int device = 0;
     int n_cus = 0;
-    int blocks_per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}}; // [LDS level][counted?]
+    int blocks_per_cu[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; // [LDS level][counted?]
     DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
     uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
     bool has_instances = false;
-    int lds_level = 0;                          // 0 nothing fits, 1 nodes only, 2 nodes + spheres + quads
+    int lds_level = 0;                          // 0 nothing fits, 1 nodes, 2 nodes + spheres, 3 nodes + spheres + quads
     uint32_t features = F_ALL;                  // Feature bits the scene uses
-    uint32_t lds_nodes_bytes = 0;               // image prefix that holds the node tables only
+    uint32_t lds_prefix_bytes[4] = {0, 0, 0, 0}; // image prefix each LDS level copies in
     DeviceArray<Node32> nodes;
     DeviceArray<Sphere> spheres;
     DeviceArray<Quad> quads;
@@ -1055,27 +1060,24 @@ constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
 constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
 uint32_t kernel_features_for(uint32_t scene_features, int lds) {
-    if (lds == 2 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
-    if (lds == 2 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
+    if (lds == 3 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
+    if (lds == 3 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
     return F_ALL;
 }
 const void *kernel_for(int lds, bool counted, uint32_t feat) {
 #define RT_PICK(L, T, F) (counted ? (const void *)path_kernel<true, L, T, F> : (const void *)path_kernel<false, L, T, F>)
-    if (lds == 2) {
-        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(2, LDS_THREADS, FEAT_SPHERES_SOLID);
-        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(2, LDS_THREADS, FEAT_QUADS_FRAMES);
-        return RT_PICK(2, LDS_THREADS, F_ALL);
+    if (lds == 3) {
+        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID);
+        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES);
+        return RT_PICK(3, LDS_THREADS, F_ALL);
     }
+    if (lds == 2) return RT_PICK(2, LDS_THREADS, F_ALL);
     if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL);
     return RT_PICK(0, GLOBAL_THREADS, F_ALL);
 #undef RT_PICK
 }
-uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return lds == 2 ? s->lds_image_bytes : lds == 1 ? s->lds_nodes_bytes : 0u; }
-size_t dynamic_lds_bytes(const rt_scene *s, int lds) {
-    const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-    const size_t world = (lds && !s->has_instances) ? 0 : (size_t)6 * threads * sizeof(double);
-    return lds_image_bytes_for(s, lds) + world;
-}
+uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return s->lds_prefix_bytes[lds]; }
+size_t dynamic_lds_bytes(const rt_scene *s, int lds) { return lds_image_bytes_for(s, lds); }
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
     dst.bytes = src.size() * sizeof(T);
@@ -1101,6 +1103,7 @@ void free_scene(rt_scene *s) {
     for (auto &kv : s->workspaces) {
         (void)hipFree(kv.second.att_stack);
         (void)hipFree(kv.second.samples);
+        (void)hipFree(kv.second.world_slots);
         (void)hipFree(kv.second.job_counter);
         (void)hipFree(kv.second.counters);
     }
@@ -1178,6 +1181,14 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             HIP_TRY(hipMalloc((void **)&w.att_stack, need_att));
             w.att_bytes = need_att;
         }
+        const size_t need_world = (size_t)6 * n_threads * sizeof(double);
+        if (w.world_bytes < need_world) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (w.world_slots) HIP_TRY(hipFree(w.world_slots));
+            w.world_slots = nullptr; w.world_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&w.world_slots, need_world));
+            w.world_bytes = need_world;
+        }
         if (w.sample_bytes < need_samples) {
             if (w.samples) HIP_TRY(hipFree(w.samples));
             w.samples = nullptr; w.sample_bytes = 0;
@@ -1210,7 +1221,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
-    K.lds_off_world = lds_image_bytes_for(scene, lds);
+    K.world_slots = ws.world_slots;
     K.th_prim = tn.th_prim; K.th_other = tn.th_other; K.th_shade = tn.th_shade; K.th_box = tn.th_box;
 
     const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
@@ -1300,30 +1311,31 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
         const size_t off_b = n * 16, off_sph = n * 32;
         const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
         const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
-        const size_t world = s->has_instances ? (size_t)6 * LDS_THREADS * sizeof(double) : 0;
-        s->lds_level = total + world <= LDS_BUDGET_BYTES ? 2 : (off_sph + world <= LDS_BUDGET_BYTES ? 1 : 0);
+        // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
+        s->lds_level = total <= LDS_BUDGET_BYTES ? 3 : (off_sph <= LDS_BUDGET_BYTES ? 1 : 0);
         if (s->lds_level) {
-            // level 1 uploads (and copies to LDS) only the node tables, the prefix of the same image
-            const size_t used = s->lds_level == 2 ? total : off_sph;
+            // every level copies a prefix of the same image: node tables | spheres | quads
+            const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
             std::vector<uint4> img(used / 16);
             unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
             for (size_t i = 0; i < n; ++i) {
                 memcpy(base + i * 16, &cs.nodes32[i], 16);
                 memcpy(base + off_b + i * 16, reinterpret_cast<const unsigned char *>(&cs.nodes32[i]) + 16, 16);
             }
-            if (s->lds_level == 2) {
-                if (!cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
-                if (!cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
-            }
+            if (s->lds_level >= 2 && !cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
+            if (s->lds_level == 3 && !cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
             int urc = upload(s->lds_image, img);
             if (urc != RT_OK) { free_scene(s); return urc; }
             s->lds_off_node_b = (uint32_t)off_b;
             s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;
             s->lds_image_bytes = (uint32_t)used;
-            s->lds_nodes_bytes = (uint32_t)off_sph;
+            s->lds_prefix_bytes[1] = (uint32_t)off_sph;
+            s->lds_prefix_bytes[2] = (uint32_t)((off_quads + 15u) & ~(size_t)15u);
+            s->lds_prefix_bytes[3] = (uint32_t)total;
+            for (int l = s->lds_level + 1; l < 4; ++l) s->lds_prefix_bytes[l] = 0;
         }
     }
-    for (int lds = 0; lds < 3; ++lds)
+    for (int lds = 0; lds < 4; ++lds)
         for (int counted = 0; counted < 2; ++counted) {
             if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
             const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds));
