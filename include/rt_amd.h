@@ -320,7 +320,8 @@ int rt_debug_stage_profile(uint64_t out[15]);
 
 /* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
  * live lanes wait for it; the box loop keeps running while th_box/64 of them are in it; use_lds = 0 forces the
- * scene to be gathered from global memory even when it fits the LDS.  Negative: keep.
+ * scene to be gathered from global memory even when it fits the LDS.  A negative threshold restores the built-in
+ * per-scene-class preset; a negative use_lds keeps the current setting.
  * Affects speed only, never results.  Process-wide; not for concurrent use with renders. */
 int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds);
 

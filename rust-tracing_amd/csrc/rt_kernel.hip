@@ -996,17 +996,33 @@ struct Workspace {
 
 // Scheduler knobs (64ths of the live lanes a deferred stage must have queued; box rounds per decision).
 // Defaults were picked on MI355X with bench.py (DESIGN.md "Scheduler"); the RT_* variables are for tuning runs.
+// Scheduler knobs (64ths of the live lanes a deferred stage must have queued / the box loop needs to keep running).
+// The best values depend on the stage mix, so there is one preset per kernel instantiation, each picked with
+// tools/tune.py on MI355X (DESIGN.md "Scheduler"); a value >= 0 in `forced` (RT_TH_* variables, rt_debug_set_tuning)
+// overrides all presets.
+struct Thresholds { uint32_t prim, other, shade, box; };
 struct Tuning {
-    uint32_t th_prim = 8, th_other = 16, th_shade = 32, th_box = 24;
+    Thresholds general{8, 8, 48, 8};         // every feature (final_scene: 679 Msamples/s at 150 spp vs 619 with the spheres preset)
+    Thresholds spheres_solid{8, 16, 40, 24}; // random-spheres
+    Thresholds quads_frames{16, 16, 56, 4};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
+    int forced[4] = {-1, -1, -1, -1};        // prim, other, shade, box
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     int refit = 1;   // 0: walk the reference's own (looser) boxes
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
-        auto env = [](const char *name, uint32_t &v) { if (const char *e = getenv(name)) v = (uint32_t)strtoul(e, nullptr, 10); };
-        env("RT_TH_PRIM", th_prim); env("RT_TH_OTHER", th_other); env("RT_TH_SHADE", th_shade); env("RT_TH_BOX", th_box);
+        auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
+        env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]);
         if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
         if (const char *e = getenv("RT_REFIT")) refit = atoi(e);
         if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
+    }
+    Thresholds pick(const Thresholds &preset) const {
+        Thresholds t = preset;
+        if (forced[0] >= 0) t.prim = (uint32_t)forced[0];
+        if (forced[1] >= 0) t.other = (uint32_t)forced[1];
+        if (forced[2] >= 0) t.shade = (uint32_t)forced[2];
+        if (forced[3] >= 0) t.box = (uint32_t)forced[3];
+        return t;
     }
 };
 Tuning &tuning() { static Tuning t; return t; }
@@ -1222,7 +1238,11 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
-    K.th_prim = tn.th_prim; K.th_other = tn.th_other; K.th_shade = tn.th_shade; K.th_box = tn.th_box;
+    {
+        const uint32_t kf = kernel_features_for(scene->features, lds);
+        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : tn.general));
+        K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box;
+    }
 
     const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
     for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk) {
@@ -1473,10 +1493,7 @@ int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count,
 
 int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds) {
     Tuning &t = tuning();
-    if (th_prim >= 0) t.th_prim = (uint32_t)th_prim;
-    if (th_other >= 0) t.th_other = (uint32_t)th_other;
-    if (th_shade >= 0) t.th_shade = (uint32_t)th_shade;
-    if (th_box >= 0) t.th_box = (uint32_t)th_box;
+    t.forced[0] = th_prim; t.forced[1] = th_other; t.forced[2] = th_shade; t.forced[3] = th_box;
     if (use_lds >= 0) t.use_lds = use_lds;
     return RT_OK;
 }
