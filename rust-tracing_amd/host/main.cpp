@@ -1,7 +1,8 @@
 // Command-line front end.  reference: src/main.rs:40-54 (Args) and :641-669 (main)
 //   -s/--scene N, -o/--output NAME as in the reference; -l/--live is accepted and refused (no window system
 //   on a GPU node).  Added: --width/--aspect/--spp/--depth (BASELINE.json's configs change these),
-//   --seed/--scene-seed, --gpus, --earth PATH|synthetic:WxH, --bvh reference|sah.
+//   --seed/--scene-seed, --gpus, --earth PATH|synthetic:WxH, --bvh reference|sah, --progressive N (rewrite the PNG
+//   every N samples per pixel: what -l/--live shows in a window, written to the file instead).
 #include "renderer.hpp"
 #include "scenes.hpp"
 #include <chrono>
@@ -15,7 +16,7 @@ using namespace rt;
 static void usage(const char *argv0) {
     fprintf(stderr,
             "Usage: %s [-s SCENE] [-o OUTPUT] [--width W] [--aspect A] [--spp N] [--depth D]\n"
-            "          [--seed S] [--scene-seed S] [--gpus N] [--earth PATH|synthetic:WxH] [--bvh reference|sah]\n"
+            "          [--seed S] [--scene-seed S] [--gpus N] [--progressive SPP_PER_PASS] [--earth PATH|synthetic:WxH] [--bvh reference|sah]\n"
             "  scenes: 0 random balls, 1 two spheres, 2 earth, 3 perlin spheres, 4 quads, 5 simple light,\n"
             "          6 cornell box, 7 cornell smoke, 8 final scene\n",
             argv0);
@@ -46,6 +47,7 @@ int main(int argc, char **argv) {
         else if (a == "--seed") ro.seed = strtoull(need("--seed"), nullptr, 10);
         else if (a == "--scene-seed") scene_seed = strtoull(need("--scene-seed"), nullptr, 10);
         else if (a == "--gpus") ro.gpus = atoi(need("--gpus"));
+        else if (a == "--progressive") ro.progressive_spp = atoi(need("--progressive"));
         else if (a == "--earth") so.earth_image = need("--earth");
         else if (a == "--bvh") bvh_policy() = std::string(need("--bvh")) == "sah" ? BvhPolicy::Sah : BvhPolicy::Reference;
         else if (a == "-h" || a == "--help") { usage(argv[0]); return 0; }

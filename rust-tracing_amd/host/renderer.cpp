@@ -9,7 +9,8 @@
 
 namespace rt {
 
-std::vector<double> render_sums(const Camera &camera, const Hittable &world, const RenderOptions &opt) {
+std::vector<double> render_sums(const Camera &camera, const Hittable &world, const RenderOptions &opt,
+                                const std::function<void(const std::vector<double> &, int)> &on_pass) {
     SceneDescriber sd;
     const rt_ref root = world.describe(sd);
     const rt_scene_desc desc = sd.desc(root);
@@ -20,30 +21,47 @@ std::vector<double> render_sums(const Camera &camera, const Hittable &world, con
         throw std::runtime_error("render: " + std::to_string(ngpu) + " GPU(s) requested, " +
                                  std::to_string(rt_device_count()) + " visible");
 
+    std::vector<rt_scene *> scenes((size_t)ngpu, nullptr);
+    auto destroy_all = [&]() { for (rt_scene *s : scenes) rt_scene_destroy(s); };
+    for (int g = 0; g < ngpu; ++g)
+        if (rt_scene_create(&desc, g, &scenes[(size_t)g]) != RT_OK) {
+            const std::string msg = rt_last_error();
+            destroy_all();
+            throw std::runtime_error("render: " + msg);
+        }
+
     std::vector<double> sums((size_t)cam.image_width * (size_t)cam.image_height * 3u, 0.0);
-    std::vector<std::string> errors((size_t)ngpu);
-    std::vector<std::thread> workers;
-    // one host thread per device; each renders the tiles k with k % ngpu == g into its own pixels of `sums`
-    for (int g = 0; g < ngpu; ++g) {
-        workers.emplace_back([&, g]() {
-            rt_scene *scene = nullptr;
-            if (rt_scene_create(&desc, g, &scene) != RT_OK) { errors[g] = rt_last_error(); return; }
-            rt_render_params p{};
-            p.seed = opt.seed;
-            p.sample_begin = 0;
-            p.sample_end = cam.samples_per_pixel;
-            p.max_depth = cam.max_depth;
-            p.shard_index = g;
-            p.shard_count = ngpu;
-            p.out_layout = RT_OUT_FRAME;
-            p.device = g;
-            if (rt_render(scene, &cam, &p, sums.data()) != RT_OK) errors[g] = rt_last_error();
-            rt_scene_destroy(scene);
-        });
+    const int spp = cam.samples_per_pixel;
+    const int pass = opt.progressive_spp > 0 ? opt.progressive_spp : spp;
+    for (int begin = 0; begin < spp; begin += pass) {
+        const int end = begin + pass < spp ? begin + pass : spp;
+        std::vector<std::string> errors((size_t)ngpu);
+        std::vector<std::thread> workers;
+        // one host thread per device; each renders the tiles k with k % ngpu == g into its own pixels of `sums`
+        for (int g = 0; g < ngpu; ++g) {
+            workers.emplace_back([&, g]() {
+                rt_render_params p{};
+                p.seed = opt.seed;
+                p.sample_begin = begin;
+                p.sample_end = end;
+                p.max_depth = cam.max_depth;
+                p.accumulate = begin > 0 ? 1 : 0;
+                p.shard_index = g;
+                p.shard_count = ngpu;
+                p.out_layout = RT_OUT_FRAME;
+                p.device = g;
+                if (rt_render(scenes[(size_t)g], &cam, &p, sums.data()) != RT_OK) errors[(size_t)g] = rt_last_error();
+            });
+        }
+        for (auto &w : workers) w.join();
+        for (const auto &e : errors)
+            if (!e.empty()) {
+                destroy_all();
+                throw std::runtime_error("render: " + e);
+            }
+        if (on_pass) on_pass(sums, end);
     }
-    for (auto &w : workers) w.join();
-    for (const auto &e : errors)
-        if (!e.empty()) throw std::runtime_error("render: " + e);
+    destroy_all();
     return sums;
 }
 
@@ -61,7 +79,14 @@ void render(std::shared_ptr<Camera> camera, std::shared_ptr<Hittable> world, con
             const RenderOptions &opt) {
     using clock = std::chrono::steady_clock;
     auto now = clock::now();
-    const std::vector<double> sums = render_sums(*camera, *world, opt);
+    const int32_t w = (int32_t)camera->image_width, h = (int32_t)camera->image_height;
+    // progressive passes: the PNG on disk always shows the mean of the samples traced so far
+    auto on_pass = [&](const std::vector<double> &partial, int done) {
+        if (opt.progressive_spp <= 0 || done >= camera->samples_per_pixel) return;
+        write_png_rgb8(output_file_name + ".png", w, h, resolve_rgb8(partial, done).data());
+        if (!opt.quiet) printf("  %d / %d spp\n", done, camera->samples_per_pixel);
+    };
+    const std::vector<double> sums = render_sums(*camera, *world, opt, on_pass);
     const double render_s = std::chrono::duration<double>(clock::now() - now).count();
     if (!opt.quiet) {
         const double msamples = (double)camera->image_width * (double)camera->image_height *

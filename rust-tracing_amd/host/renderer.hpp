@@ -6,6 +6,7 @@
 #pragma once
 #include "camera.hpp"
 #include "hittable.hpp"
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -16,11 +17,17 @@ struct RenderOptions {
     uint64_t seed = 1; // render seed (the reference's RNG is unseeded; see include/rt_amd.h "RNG")
     int gpus = 1;      // framebuffer tiles are dealt round-robin to this many devices
     bool quiet = false;
+    // > 0: render in passes of this many samples per pixel and rewrite the PNG after every pass — the batch
+    // counterpart of the reference's live_render (src/renderer.rs:77-137: one more sample per frame, running mean),
+    // without the window.  The final image is bit-identical to a single-pass render (ranges accumulate exactly).
+    int progressive_spp = 0;
 };
 
 // Returns the per-pixel sums (w*h*3 doubles, row-major) exactly like the reference's `raw_pixels`
 // (src/renderer.rs:26-49).  Throws std::runtime_error if the GPU library reports an error.
-std::vector<double> render_sums(const Camera &camera, const Hittable &world, const RenderOptions &opt = {});
+// `on_pass(sums, samples_done)`, if given, is called after every progressive pass.
+std::vector<double> render_sums(const Camera &camera, const Hittable &world, const RenderOptions &opt = {},
+                                const std::function<void(const std::vector<double> &, int)> &on_pass = nullptr);
 
 // color_to_rgb(c / spp) over the whole frame (src/renderer.rs:55-58)
 std::vector<uint8_t> resolve_rgb8(const std::vector<double> &sums, int32_t spp);

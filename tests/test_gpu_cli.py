@@ -1,0 +1,32 @@
+"""The command-line renderer (rust-tracing_amd/host/main.cpp, the reference's `main`): runs on the GPU, writes the PNG
+the Python path produces for the same scene and seeds, single-pass or progressive."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rtrace_writes_the_same_png_as_the_library_path(rt, gpu, tmp_path):
+    from PIL import Image
+    exe = rt.LIB_DIR / "rtrace"
+    assert exe.exists(), "run build() first"
+    args = ["-s", "6", "--width", "96", "--spp", "24", "--depth", "8", "--seed", "5", "--scene-seed", "1"]
+    out1 = tmp_path / "single"
+    r = subprocess.run([str(exe), *args, "-o", str(out1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Building BVH" in r.stdout and "Render time" in r.stdout and "PNG encoding" in r.stdout  # the reference's three timings
+    out2 = tmp_path / "progressive"
+    r = subprocess.run([str(exe), *args, "--progressive", "7", "-o", str(out2)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a = np.asarray(Image.open(str(out1) + ".png").convert("RGB"))
+    b = np.asarray(Image.open(str(out2) + ".png").convert("RGB"))
+    assert a.shape == (96, 96, 3) and np.array_equal(a, b)
+    hs = rt.HostScene(6, scene_seed=1, width=96, spp=24, depth=8)
+    sums = rt.DeviceScene(hs).render(rt.render_params(seed=5))
+    assert np.array_equal(rt.resolve_rgb8_host(96, 96, 24, sums), a)
+    # -l/--live needs a window system: refused, not ignored
+    r = subprocess.run([str(exe), "-l"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "live" in r.stderr
