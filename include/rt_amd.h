@@ -313,6 +313,19 @@ int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, doubl
 int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax,
                        uint8_t *out_exact_hit, uint8_t *out_f32_hit, int device);
 
+/* Test hook (no GPU needed): runs the scene compiler and returns the records the device would walk — the f64 box each
+ * carries after refitting (refit != 0) or as the reference has it (refit == 0), the outward-rounded f32 box actually
+ * tested, the threaded links, and the bound of the record's own primitives — so that tests can check the compiler's
+ * invariants (links, containment) on the CPU.  out_nodes may be NULL to query the count. */
+typedef struct rt_debug_node {
+    double lo[3], hi[3];           /* box of the record (f64) */
+    float lo32[3], hi32[3];        /* what the kernel tests */
+    double prim_lo[3], prim_hi[3]; /* bound of the leaf's own primitives (+inf/-inf if none) */
+    uint32_t skip, kind, no_bbox, a, b, _pad;
+} rt_debug_node;
+int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity,
+                            int64_t *out_count);
+
 /* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
  * (box, sphere, quad, other, shade): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
  * summed over waves. */

@@ -160,6 +160,12 @@ class SceneOptions(C.Structure):
                 ("max_depth", C.c_int32), ("earth_image", C.c_char_p)]
 
 
+class DebugNode(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3), ("lo32", C.c_float * 3), ("hi32", C.c_float * 3),
+                ("prim_lo", C.c_double * 3), ("prim_hi", C.c_double * 3), ("skip", C.c_uint32), ("kind", C.c_uint32),
+                ("no_bbox", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class RtError(RuntimeError):
     pass
 
@@ -181,6 +187,8 @@ RT_AMD_SYMBOLS = {
                                 C.POINTER(C.c_double), C.c_int]),
     "rt_debug_box_tests": (C.c_int, [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                      C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int]),
+    "rt_debug_compiled_nodes": (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.POINTER(DebugNode), C.c_int64,
+                                          C.POINTER(C.c_int64)]),
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
     "rt_debug_set_tuning": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_last_error": (C.c_char_p, []),
@@ -204,6 +212,17 @@ def debug_box_tests(rays, boxes, tmin, tmax, device=0):
                                         exact.ctypes.data_as(C.POINTER(C.c_uint8)), f32.ctypes.data_as(C.POINTER(C.c_uint8)),
                                         device), "rt_debug_box_tests")
     return exact.astype(bool), f32.astype(bool)
+
+
+def debug_compiled_nodes(host_scene, refit=True):
+    """rt_debug_compiled_nodes: the records the device walks for this scene (runs on the CPU)."""
+    n = C.c_int64()
+    _check(amd_lib().rt_debug_compiled_nodes(C.byref(host_scene.desc), 1 if refit else 0, None, 0, C.byref(n)),
+           "rt_debug_compiled_nodes")
+    buf = (DebugNode * n.value)()
+    _check(amd_lib().rt_debug_compiled_nodes(C.byref(host_scene.desc), 1 if refit else 0, buf, n.value, C.byref(n)),
+           "rt_debug_compiled_nodes")
+    return buf
 
 
 def debug_stage_profile() -> dict:

@@ -1498,6 +1498,55 @@ int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int
     return RT_OK;
 }
 
+int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity, int64_t *out_count) {
+    if (!desc || !out_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: null argument");
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc, refit != 0);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_compiled_nodes: ") + e.what());
+    }
+    *out_count = (int64_t)cs.nodes.size();
+    if (!out_nodes) return RT_OK;
+    if ((int64_t)cs.nodes.size() > capacity) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: buffer too small");
+    for (size_t i = 0; i < cs.nodes.size(); ++i) {
+        const Node &n = cs.nodes[i];
+        const Node32 &m = cs.nodes32[i];
+        rt_debug_node &o = out_nodes[i];
+        for (int k = 0; k < 3; ++k) { o.lo[k] = n.lo[k]; o.hi[k] = n.hi[k]; }
+        o.lo32[0] = m.bx[0]; o.hi32[0] = m.bx[1]; o.lo32[1] = m.by[0]; o.hi32[1] = m.by[1]; o.lo32[2] = m.bz[0]; o.hi32[2] = m.bz[1];
+        o.skip = n.skip; o.kind = n.kind & NODE_KIND_MASK; o.no_bbox = (n.kind & NODE_NO_BBOX) ? 1u : 0u; o.a = n.a; o.b = n.b;
+        o.prim_lo[0] = o.prim_lo[1] = o.prim_lo[2] = INFINITY;
+        o.prim_hi[0] = o.prim_hi[1] = o.prim_hi[2] = -INFINITY;
+        // bound of the record's own primitives (leaves), in the frame the record lives in
+        auto grow = [&](double x, double y, double z) {
+            const double p[3] = {x, y, z};
+            for (int k = 0; k < 3; ++k) { o.prim_lo[k] = std::fmin(o.prim_lo[k], p[k]); o.prim_hi[k] = std::fmax(o.prim_hi[k], p[k]); }
+        };
+        if (o.kind == NK_SPHERES || o.kind == NK_MEDIUM_SPHERE) {
+            const uint32_t first = o.kind == NK_SPHERES ? n.a : cs.media[n.a].first_node, count = o.kind == NK_SPHERES ? n.b : 1u;
+            for (uint32_t q = first; q < first + count; ++q) {
+                const Sphere &sp = cs.spheres[q];
+                for (int e = 0; e < (sp.is_moving ? 2 : 1); ++e) {
+                    const double c[3] = {sp.center[0] + e * sp.center_vec[0], sp.center[1] + e * sp.center_vec[1], sp.center[2] + e * sp.center_vec[2]};
+                    grow(c[0] - sp.radius, c[1] - sp.radius, c[2] - sp.radius);
+                    grow(c[0] + sp.radius, c[1] + sp.radius, c[2] + sp.radius);
+                }
+            }
+        } else if (o.kind == NK_QUADS) {
+            for (uint32_t q = n.a; q < n.a + n.b; ++q) {
+                const Quad &qd = cs.quads[q];
+                for (int i2 = 0; i2 < 2; ++i2)
+                    for (int j2 = 0; j2 < 2; ++j2)
+                        grow(qd.q[0] + i2 * qd.u[0] + j2 * qd.v[0], qd.q[1] + i2 * qd.u[1] + j2 * qd.v[1], qd.q[2] + i2 * qd.u[2] + j2 * qd.v[2]);
+            }
+        }
+    }
+    return RT_OK;
+}
+
 int rt_debug_stage_profile(uint64_t out[15]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
     std::lock_guard<std::mutex> lock(g_stage_profile_mu);
