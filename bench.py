@@ -161,11 +161,21 @@ def main():
     # --- outside the timed region: work counters (instrumented kernel, reduced spp), sanity, CPU baseline ---
     result = None
     if rank == 0:
+        # ALGORITHMIC work per sample (DESIGN.md "Roofline"): the events of the flat left-first walk of
+        # the reference's tree with the tight box test — counted by the instrumented kernel made to walk exactly that
+        # (it agrees with the oracle's tight-mode counters, tests/test_gpu_parity.py).  What the shipped kernel
+        # executes instead (its own trees, nearest child first, where the scene allows) is reported next to it.
         cnt_spp = min(spp, 4)
         scratch = torch.zeros(w * h * 3, dtype=torch.float64, device=dev)
-        cnt = scene.render_device_counted(rt.render_params(seed=RENDER_SEED, sample_end=cnt_spp), scratch.data_ptr(),
-                                          stream.cuda_stream)
+        cnt_params = rt.render_params(seed=RENDER_SEED, sample_end=cnt_spp)
+        executed = scene.render_device_counted(cnt_params, scratch.data_ptr(), stream.cuda_stream)
+        rt.amd_lib().rt_debug_set_traversal(0, -1)
+        ref_walk = rt.DeviceScene(hs, device=local_rank)
+        rt.amd_lib().rt_debug_set_traversal(1, -1)
+        cnt = ref_walk.render_device_counted(cnt_params, scratch.data_ptr(), stream.cuda_stream)
+        del ref_walk
         flops_ps, bytes_ps, per = algorithmic_work_per_sample(cnt)
+        executed_per = {k: v / max(1, executed["samples"]) for k, v in executed.items()}
         samples_per_launch = w * h * spp / world
         k_ms = sum(kernel_ms) / len(kernel_ms)
         tflops = flops_ps * samples_per_launch / (k_ms * 1e-3) / 1e12
@@ -196,6 +206,8 @@ def main():
                 "kernel": "path_kernel<false>", "kernel_ms": round(k_ms, 3),
                 "algorithmic_flops_per_sample": round(flops_ps, 1), "algorithmic_bytes_per_sample": round(bytes_ps, 1),
                 "events_per_sample": {k: round(v, 3) for k, v in per.items() if k != "samples"},
+                "executed_events_per_sample": {k: round(v, 3) for k, v in executed_per.items() if k != "samples"},
+                "walk": "own trees, nearest child first" if scene.stats()["ordered"] else "reference tree, reference order",
                 "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 5)},
             },

@@ -260,7 +260,8 @@ typedef struct rt_scene_stats {
     uint64_t node_bytes, sphere_bytes, quad_bytes, instance_bytes, medium_bytes, material_bytes,
         texture_bytes, perlin_bytes, image_bytes;
     uint32_t n_nodes, n_spheres, n_quads, n_instances, n_media, max_instance_depth;
-    uint32_t lds_nodes, lds_bytes;
+    uint32_t lds_nodes, lds_bytes;      /* records resident in the LDS; LDS bytes a workgroup uses (image + stacks) */
+    uint32_t ordered, stack_entries;    /* 1: the scene is walked through the library's own trees (DESIGN.md "Ordered walk") */
 } rt_scene_stats;
 int rt_scene_get_stats(const rt_scene *scene, rt_scene_stats *out);
 
@@ -325,6 +326,27 @@ typedef struct rt_debug_node {
 } rt_debug_node;
 int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity,
                             int64_t *out_count);
+
+/* Test / tuning hook: how scenes created from now on are walked.  ordered = 1 (default): scenes without a
+ * ConstantMedium use the library's own trees, nearest child first; 0: every scene walks the reference's tree in the
+ * reference's order.  leaf_max > 0: primitives per leaf of those trees at most.  Negative / zero: keep.
+ * Affects speed only, never results. */
+int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
+
+/* Test hook: the ordered layout the scene compiler builds for `desc` (no device needed).  Set the cap_* fields and
+ * the pointers (any may be null: only the counts are returned then).
+ * nodes: 16 words per record = two boxes as 6 floats (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi), two child references
+ * (kind << 29 | (count - 1) << 26 | index; kind 0 record, 1 spheres, 2 quads, 3 instance, 7 empty), 2 unused.
+ * spheres: 9 doubles = center, radius, center_vec, seq, is_moving.  quads: 10 = q, u, v, seq.
+ * instances: 8 = offset, sin, cos, parent, flags (1 translate, 2 rotate), root record. */
+typedef struct rt_debug_ordered {
+    int64_t cap_nodes, cap_spheres, cap_quads, cap_instances;
+    int64_t n_nodes, n_spheres, n_quads, n_instances;
+    uint32_t ordered, root, stack_entries, _pad;
+    uint32_t *nodes;
+    double *spheres, *quads, *instances;
+} rt_debug_ordered;
+int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
 
 /* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
  * (box, sphere, quad, other, shade): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)

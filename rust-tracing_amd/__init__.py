@@ -148,7 +148,8 @@ class SceneStats(C.Structure):
                                           "medium_bytes", "material_bytes", "texture_bytes", "perlin_bytes",
                                           "image_bytes")] + \
                [(n, C.c_uint32) for n in ("n_nodes", "n_spheres", "n_quads", "n_instances", "n_media",
-                                          "max_instance_depth", "lds_nodes", "lds_bytes")]
+                                          "max_instance_depth", "lds_nodes", "lds_bytes", "ordered",
+                                          "stack_entries")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -190,6 +191,8 @@ RT_AMD_SYMBOLS = {
     "rt_debug_compiled_nodes": (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.POINTER(DebugNode), C.c_int64,
                                           C.POINTER(C.c_int64)]),
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "rt_debug_set_traversal": (C.c_int, [C.c_int32, C.c_int32]),
+    "rt_debug_ordered_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_debug_set_tuning": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
@@ -223,6 +226,29 @@ def debug_compiled_nodes(host_scene, refit=True):
     _check(amd_lib().rt_debug_compiled_nodes(C.byref(host_scene.desc), 1 if refit else 0, buf, n.value, C.byref(n)),
            "rt_debug_compiled_nodes")
     return buf
+
+
+class DebugOrdered(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("cap_nodes", "cap_spheres", "cap_quads", "cap_instances",
+                                         "n_nodes", "n_spheres", "n_quads", "n_instances")] + \
+               [(n, C.c_uint32) for n in ("ordered", "root", "stack_entries", "_pad")] + \
+               [("nodes", C.c_void_p), ("spheres", C.c_void_p), ("quads", C.c_void_p), ("instances", C.c_void_p)]
+
+
+def debug_ordered_layout(host_scene) -> dict:
+    """rt_debug_ordered_layout: the scene compiler's ordered layout (numpy arrays), no device needed."""
+    import numpy as np
+    io = DebugOrdered()
+    _check(amd_lib().rt_debug_ordered_layout(C.addressof(host_scene.desc), C.addressof(io)), "rt_debug_ordered_layout")
+    nodes = np.zeros((max(io.n_nodes, 1), 16), dtype=np.uint32)
+    spheres = np.zeros((max(io.n_spheres, 1), 9)); quads = np.zeros((max(io.n_quads, 1), 10))
+    insts = np.zeros((max(io.n_instances, 1), 8))
+    io.cap_nodes, io.cap_spheres, io.cap_quads, io.cap_instances = len(nodes), len(spheres), len(quads), len(insts)
+    io.nodes, io.spheres, io.quads, io.instances = (a.ctypes.data for a in (nodes, spheres, quads, insts))
+    _check(amd_lib().rt_debug_ordered_layout(C.addressof(host_scene.desc), C.addressof(io)), "rt_debug_ordered_layout")
+    return {"ordered": bool(io.ordered), "root": int(io.root), "stack_entries": int(io.stack_entries),
+            "nodes": nodes[:io.n_nodes], "spheres": spheres[:io.n_spheres], "quads": quads[:io.n_quads],
+            "instances": insts[:io.n_instances]}
 
 
 def debug_stage_profile() -> dict:

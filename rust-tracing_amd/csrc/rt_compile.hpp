@@ -15,9 +15,82 @@ struct CompileError : std::runtime_error {
     CompileError(int st, const std::string &m) : std::runtime_error(m), status(st) {}
 };
 
+// ---- bounds of the geometry (box refit, ordered trees) ---------------------------------------------------
+struct Bound {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool empty() const { return !(lo[0] <= hi[0]); }
+    void add_point(double x, double y, double z) {
+        const double p[3] = {x, y, z};
+        for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], p[k]); hi[k] = std::fmax(hi[k], p[k]); }
+    }
+    void add(const Bound &b) {
+        if (b.empty()) return;
+        for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], b.lo[k]); hi[k] = std::fmax(hi[k], b.hi[k]); }
+    }
+};
+inline Bound sphere_bound(const Sphere &s) {
+    Bound b;
+    for (int e = 0; e < 2; ++e) { // both ends of the motion (time in [0, 1), src/sphere.rs:34-46)
+        const double c[3] = {s.center[0] + (e ? s.center_vec[0] : 0.0), s.center[1] + (e ? s.center_vec[1] : 0.0),
+                             s.center[2] + (e ? s.center_vec[2] : 0.0)};
+        const double r = std::fabs(s.radius);
+        b.add_point(c[0] - r, c[1] - r, c[2] - r);
+        b.add_point(c[0] + r, c[1] + r, c[2] + r);
+        if (!(s.seq_moving & 1u)) break;
+    }
+    return b;
+}
+inline Bound quad_bound(const Quad &q) {
+    Bound b;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            b.add_point(q.q[0] + i * q.u[0] + j * q.v[0], q.q[1] + i * q.u[1] + j * q.v[1], q.q[2] + i * q.u[2] + j * q.v[2]);
+    return b;
+}
+// The box a record carries for geometry bounded by `b`: an axis the geometry is flat on (a quad) gets the thickness the
+// reference's AABB::pad gives it (src/aabb.rs:35-53), and every face moves out by a few ulps because hit points are
+// computed with rounding and may sit a hair outside the exact shape.
+inline void pad_axis(double &lo, double &hi) {
+    if (hi - lo < 0.0001) { lo -= 0.00005; hi += 0.00005; }
+    const double slack = 8.0 * 2.220446049250313e-16 * std::fmax(std::fabs(lo), std::fabs(hi));
+    lo -= slack; hi += slack;
+}
+// a frame's bound seen from the enclosing frame: rotate the eight corners, then shift (src/hittable.rs:126-149,:88)
+inline Bound instance_bound(const Instance &in, const Bound &inner) {
+    Bound b;
+    if (inner.empty()) return b;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int l = 0; l < 2; ++l) {
+                double x = i ? inner.hi[0] : inner.lo[0], y = j ? inner.hi[1] : inner.lo[1], z = l ? inner.hi[2] : inner.lo[2];
+                if (in.flags & INST_ROTATE) {
+                    const double nx = in.cos_theta * x + in.sin_theta * z, nz = -in.sin_theta * x + in.cos_theta * z;
+                    x = nx; z = nz;
+                }
+                if (in.flags & INST_TRANSLATE) { x += in.offset[0]; y += in.offset[1]; z += in.offset[2]; }
+                b.add_point(x, y, z);
+            }
+    return b;
+}
+// f64 -> f32 rounded towards -inf / +inf
+inline float round_down(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+inline float round_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
 struct CompiledScene {
     std::vector<Node> nodes;     // f64 boxes (build-time)
     std::vector<Node32> nodes32; // what the device walks
+    // ordered layout (rt_ordered.hpp), when the scene allows it: the primitive tables are then in leaf order
+    bool ordered = false;
+    std::vector<ONode> onodes;
+    uint32_t ordered_root = 0, ordered_stack = 0; // world root record; stack entries a lane needs at most
     std::vector<Sphere> spheres;
     std::vector<Quad> quads;
     std::vector<Instance> instances;
@@ -67,6 +140,7 @@ class Compiler {
   private:
     const rt_scene_desc &d_;
     bool refit_;
+    uint32_t next_seq_ = 0; // spheres and quads are created in the reference's scan order
     CompiledScene out_;
 
     // ---- box refit ------------------------------------------------------------------------------------------
@@ -76,37 +150,6 @@ class Compiler {
     // walk only needs boxes that CONTAIN their geometry (a tighter box rejects more rays whose line or interval
     // cannot reach anything inside, never one that can: DESIGN.md "Box test"), so every record's box is replaced
     // by the intersection of the reference's box with the bound of the primitives actually below it.
-    struct Bound {
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        bool empty() const { return !(lo[0] <= hi[0]); }
-        void add_point(double x, double y, double z) {
-            const double p[3] = {x, y, z};
-            for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], p[k]); hi[k] = std::fmax(hi[k], p[k]); }
-        }
-        void add(const Bound &b) {
-            if (b.empty()) return;
-            for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], b.lo[k]); hi[k] = std::fmax(hi[k], b.hi[k]); }
-        }
-    };
-    Bound sphere_bound(const Sphere &s) const {
-        Bound b;
-        for (int e = 0; e < 2; ++e) { // both ends of the motion (time in [0, 1), src/sphere.rs:34-46)
-            const double c[3] = {s.center[0] + (e ? s.center_vec[0] : 0.0), s.center[1] + (e ? s.center_vec[1] : 0.0),
-                                 s.center[2] + (e ? s.center_vec[2] : 0.0)};
-            const double r = std::fabs(s.radius);
-            b.add_point(c[0] - r, c[1] - r, c[2] - r);
-            b.add_point(c[0] + r, c[1] + r, c[2] + r);
-            if (!s.is_moving) break;
-        }
-        return b;
-    }
-    Bound quad_bound(const Quad &q) const {
-        Bound b;
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j)
-                b.add_point(q.q[0] + i * q.u[0] + j * q.v[0], q.q[1] + i * q.u[1] + j * q.v[1], q.q[2] + i * q.u[2] + j * q.v[2]);
-        return b;
-    }
     // bound of the records [begin, end) (siblings), in the frame they live in
     Bound refit_range(uint32_t begin, uint32_t end) {
         Bound all;
@@ -128,21 +171,7 @@ class Compiler {
         case NK_MEDIUM_ENTER: b = refit_range(k + 1, n.skip - 1); break; // the boundary's geometry
         case NK_MEDIUM_SPHERE: b = sphere_bound(out_.spheres[out_.media[n.a].first_node]); break;
         case NK_INST_ENTER: {
-            const Bound inner = refit_range(k + 1, n.skip - 1);
-            if (!inner.empty()) { // back to the enclosing frame: rotate the eight corners, then shift (src/hittable.rs:126-149,:88)
-                const Instance &in = out_.instances[n.a];
-                for (int i = 0; i < 2; ++i)
-                    for (int j = 0; j < 2; ++j)
-                        for (int l = 0; l < 2; ++l) {
-                            double x = i ? inner.hi[0] : inner.lo[0], y = j ? inner.hi[1] : inner.lo[1], z = l ? inner.hi[2] : inner.lo[2];
-                            if (in.flags & INST_ROTATE) {
-                                const double nx = in.cos_theta * x + in.sin_theta * z, nz = -in.sin_theta * x + in.cos_theta * z;
-                                x = nx; z = nz;
-                            }
-                            if (in.flags & INST_TRANSLATE) { x += in.offset[0]; y += in.offset[1]; z += in.offset[2]; }
-                            b.add_point(x, y, z);
-                        }
-            }
+            b = instance_bound(out_.instances[n.a], refit_range(k + 1, n.skip - 1)); // back to the enclosing frame
             break;
         }
         default: break; // NK_INST_EXIT, NK_MEDIUM_EXIT: no geometry of their own
@@ -150,11 +179,7 @@ class Compiler {
         if (!(n.kind & NODE_NO_BBOX) && !b.empty()) {
             for (int ax = 0; ax < 3; ++ax) {
                 double lo = b.lo[ax], hi = b.hi[ax];
-                // flat on this axis (a quad): give it the thickness the reference's AABB::pad does (src/aabb.rs:35-53)
-                if (hi - lo < 0.0001) { lo -= 0.00005; hi += 0.00005; }
-                // widen by a few ulps: hit points are computed with rounding and may sit a hair outside the exact shape
-                const double slack = 8.0 * 2.220446049250313e-16 * std::fmax(std::fabs(lo), std::fabs(hi));
-                lo -= slack; hi += slack;
+                pad_axis(lo, hi);
                 n.lo[ax] = std::fmax(n.lo[ax], lo);
                 n.hi[ax] = std::fmin(n.hi[ax], hi);
             }
@@ -162,17 +187,6 @@ class Compiler {
         return b;
     }
 
-    // f64 -> f32 rounded towards -inf / +inf
-    static float round_down(double x) {
-        float f = (float)x;
-        if ((double)f > x) f = std::nextafterf(f, -INFINITY);
-        return f;
-    }
-    static float round_up(double x) {
-        float f = (float)x;
-        if ((double)f < x) f = std::nextafterf(f, INFINITY);
-        return f;
-    }
     void pack_nodes() {
         out_.nodes32.resize(out_.nodes.size());
         for (size_t i = 0; i < out_.nodes.size(); ++i) {
@@ -270,7 +284,7 @@ class Compiler {
         o.radius = s.radius;
         o.center_vec[0] = s.center_vec.x; o.center_vec[1] = s.center_vec.y; o.center_vec[2] = s.center_vec.z;
         o.material = (uint32_t)s.material;
-        o.is_moving = s.is_moving ? 1u : 0u;
+        o.seq_moving = (next_seq_++ << 1) | (s.is_moving ? 1u : 0u);
         out_.spheres.push_back(o);
         return (uint32_t)out_.spheres.size() - 1u;
     }
@@ -284,6 +298,7 @@ class Compiler {
         for (int k = 0; k < 5; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
         o.d = q.d;
         o.material = (uint32_t)q.material;
+        o.seq = next_seq_++;
         out_.quads.push_back(o);
         return (uint32_t)out_.quads.size() - 1u;
     }

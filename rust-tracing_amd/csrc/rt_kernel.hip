@@ -12,6 +12,7 @@
 // divergence plus scene-data gathers (DESIGN.md "Roofline").
 #include "rt_amd.h"
 #include "rt_compile.hpp"
+#include "rt_ordered.hpp"
 #include "rt_device_math.h"
 #include "rt_layout.h"
 
@@ -79,6 +80,10 @@ struct KParams {
     uint32_t lds_image_bytes;
     uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
     double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
+    // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
+    const ONode *onodes;
+    uint32_t o_root;
+    uint32_t lds_stack_off;
 };
 
 struct Counts {
@@ -258,6 +263,32 @@ template <int LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned ch
     return n;
 }
 
+// Ordered layout: one record = four 16-byte quarters (child 0's box | its z and child 1's x | child 1's y, z | the two
+// child references); in the LDS each quarter is a table of its own, for the same bank-spreading reason as above.
+struct ONodeData {
+    float b0[6], b1[6];
+    uint32_t c0, c1;
+};
+template <int LDS> RT_DEV ONodeData load_onode(const KParams &P, const unsigned char *lds, uint32_t id) {
+    float4 q0, q1, q2, q3;
+    if constexpr (LDS != 0) {
+        const uint32_t quarter = P.lds_off_node_b; // bytes per table
+        q0 = reinterpret_cast<const float4 *>(lds)[id];
+        q1 = reinterpret_cast<const float4 *>(lds + quarter)[id];
+        q2 = reinterpret_cast<const float4 *>(lds + 2u * quarter)[id];
+        q3 = reinterpret_cast<const float4 *>(lds + 3u * quarter)[id];
+    } else {
+        const float4 *np = reinterpret_cast<const float4 *>(&P.onodes[id]);
+        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+    }
+    ONodeData n;
+    n.b0[0] = q0.x; n.b0[1] = q0.y; n.b0[2] = q0.z; n.b0[3] = q0.w; n.b0[4] = q1.x; n.b0[5] = q1.y;
+    n.b1[0] = q1.z; n.b1[1] = q1.w; n.b1[2] = q2.x; n.b1[3] = q2.y; n.b1[4] = q2.z; n.b1[5] = q2.w;
+    n.c0 = __float_as_uint(q3.x);
+    n.c1 = __float_as_uint(q3.y);
+    return n;
+}
+
 // f32 copies of a ray for the conservative box test: origin, 1/d, and a bound E on how far rounding the origin to
 // f32 can move a slab distance on each axis; `degenerate`: some 1/d or E is not finite -> every box is entered.
 struct Ray32 {
@@ -299,6 +330,21 @@ RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, f
     const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
     return !r.degenerate && gap > tol; // a NaN compares false: pass
 }
+// The same test on a box held as (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi); also returns where the ray enters it (for
+// choosing which child to walk first: any choice is correct, the nearer one prunes more)
+RT_DEV bool box_miss_f32_enter(const float b[6], const Ray32 &r, float tmin32, float tmax32, float &enter_out) {
+    const float t0x = (b[0] - r.ox) * r.ix, t1x = (b[1] - r.ox) * r.ix;
+    const float t0y = (b[2] - r.oy) * r.iy, t1y = (b[3] - r.oy) * r.iy;
+    const float t0z = (b[4] - r.oz) * r.iz, t1z = (b[5] - r.oz) * r.iz;
+    const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x) - r.ex, __builtin_fminf(t0y, t1y) - r.ey),
+                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z) - r.ez, tmin32));
+    const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x) + r.ex, __builtin_fmaxf(t0y, t1y) + r.ey),
+                                        __builtin_fminf(__builtin_fmaxf(t0z, t1z) + r.ez, tmax32));
+    const float gap = enter - leave;
+    const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
+    enter_out = enter;
+    return !r.degenerate && gap > tol; // a NaN compares false: pass
+}
 // The exact f64 test the kernel used before (and the oracle's tight mode): kept as the yardstick for the test hook
 RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, double tmin, double tmax) {
     const double od[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
@@ -325,16 +371,19 @@ enum Feature : uint32_t {
 constexpr uint32_t F_ALL = 31u;
 
 // LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = + sphere table; 3 = + quad table
-template <bool COUNT, int LDS, int THREADS, uint32_t FEAT>
+// ORDERED: walk the compiler's own trees nearest child first (scenes without a ConstantMedium), else the threaded
+// records in the reference's order
+template <bool COUNT, int LDS, int THREADS, uint32_t FEAT, bool ORDERED>
 __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
                    HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
     constexpr bool HAS_OTHER = HAS_FRAMES || HAS_MEDIA;
+    static_assert(!(ORDERED && HAS_MEDIA), "a ConstantMedium needs the reference's visiting order");
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    if constexpr (LDS != 0) {
+    if constexpr (LDS != 0) { // (the per-lane stacks of the ordered walk follow the image)
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
         for (uint32_t k = threadIdx.x; k < P.lds_image_bytes / 16u; k += THREADS) dst[k] = P.lds_image[k];
         __syncthreads();
@@ -368,6 +417,52 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     uint32_t mode = 0; // ConstantMedium: 0 outside, 1 first boundary query, 2 second; bit 8: boundary was hit
     uint32_t stage = ST_SHADE;
     bool need_job = true;
+    // ---- ordered walk: a stack of children set aside (one entry per level at most), in the LDS, [level][thread] ----
+    // entry < S_TOP: an inner record to visit; S_TOP | (record << 1 | slot): a leaf child whose box is tested again when
+    // its turn comes (the interval has usually shrunk by then); S_EXIT: leave the current frame
+    using StackT = std::conditional_t<LDS != 0, uint16_t, uint32_t>;
+    constexpr uint32_t S_TOP = LDS != 0 ? 0x8000u : 0x80000000u, S_EXIT = LDS != 0 ? 0xffffu : 0xffffffffu;
+    constexpr uint32_t SKIP_CHILD0 = 0x40000000u, SKIP_CHILD1 = 0x80000000u, NODE_INDEX = 0x3fffffffu, NODE_FRAME_EXIT = 0xffffffffu;
+    StackT *const stack = reinterpret_cast<StackT *>(lds_raw + P.lds_stack_off) + threadIdx.x;
+    uint32_t sp = 0;
+    const uint32_t first_node = ORDERED ? P.o_root : 0u;
+    // what a lane does next in an ordered walk: go to `ref` if it has one, else take the last child set aside
+    auto o_next = [&](bool have, uint32_t ref) {
+        if (!have) {
+            if (sp == 0) { stage = ST_SHADE; return; }
+            sp--;
+            const uint32_t e = stack[sp * THREADS];
+            if (e == S_EXIT) { node = NODE_FRAME_EXIT; stage = ST_OTHER; return; }
+            if (e & S_TOP) {
+                const uint32_t ps = e & (S_TOP - 1u);
+                node = (ps >> 1) | ((ps & 1u) ? SKIP_CHILD0 : SKIP_CHILD1);
+                stage = ST_BOX;
+                return;
+            }
+            ref = e;
+        }
+        // OrderedKind INNER / SPHERES / QUADS / INSTANCE = 0 / 1 / 2 / 3 = Stage ST_BOX / ST_SPHERE / ST_QUAD / ST_OTHER
+        const uint32_t kind = ref >> OREF_KIND_SHIFT;
+        stage = kind;
+        if (kind == OK_SPHERES || kind == OK_QUADS) {
+            prim_cur = ref & OREF_INDEX_MASK;
+            prim_end = prim_cur + ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u;
+        } else {
+            node = ref & OREF_INDEX_MASK;
+        }
+    };
+    // ties (ordered walk): two primitives hit at exactly the same t.  The reference scans in a fixed order and keeps the
+    // first unless a later one passes its interval test: Sphere::hit wants t < closest (Interval::surrounds,
+    // src/sphere.rs:70-76), Quad::hit t <= closest (Interval::contains, src/quad.rs:105-107) — so of two primitives
+    // at the same t the later one in scan order wins iff it is a quad.  That relation is a total order (a later quad beats
+    // everything before it, a sphere nothing), so applying it pairwise in ANY visiting order ends with the primitive the
+    // reference's scan ends with.  `seq` is the scan position.
+    auto wins_tie = [&](uint32_t my_seq, bool i_am_quad) -> bool {
+        const bool best_is_quad = (best_prim & PRIM_KIND_MASK) == PRIM_QUAD;
+        const uint32_t bi = best_prim & PRIM_INDEX_MASK;
+        const uint32_t best_seq = best_is_quad ? quad_tab[bi].seq : (sphere_tab[bi].seq_moving >> 1);
+        return my_seq > best_seq ? i_am_quad : !best_is_quad;
+    };
 
     double *att = P.att_stack + (size_t)gtid * 3u;
     const size_t att_stride = (size_t)P.n_threads * 3u;
@@ -427,25 +522,48 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             // stays in this loop (one ballot per round) while enough of the wave's live lanes are walking boxes
             uint32_t in_box;
             do {
-                if (stage == ST_BOX) {
-                    const NodeData nd = load_node<LDS>(P, lds_raw, node);
-                    if (COUNT) cn.node_visits += (nd.packed & N32_NO_BBOX) ? 0u : 1u;
-                    const bool miss = box_miss_f32(nd.lo, nd.hi, r32, tmin32, tmax32);
-                    // dispatch on the record kind, branch-free: INNER (0) walks on to the next record, a leaf (1, 2)
-                    // queues for its primitive stage and will continue at `skip`, anything else (>= 3) queues for ST_OTHER
-                    const uint32_t kind = nd.packed & N32_KIND_MASK;
-                    const uint32_t a_field = nd.packed >> N32_A_SHIFT;
-                    const bool is_leaf = kind == NK_SPHERES || kind == NK_QUADS;
-                    if (!miss && is_leaf) {
-                        prim_cur = a_field;
-                        prim_end = a_field + ((nd.packed >> N32_COUNT_SHIFT) & N32_COUNT_MASK);
+                if constexpr (ORDERED) {
+                    if (stage == ST_BOX) {
+                        // one record: both children's boxes; walk the nearer one, set the other aside
+                        const uint32_t nid = node & NODE_INDEX;
+                        const ONodeData nd = load_onode<LDS>(P, lds_raw, nid);
+                        if (COUNT) cn.node_visits++;
+                        float e0, e1;
+                        bool h0 = !box_miss_f32_enter(nd.b0, r32, tmin32, tmax32, e0);
+                        bool h1 = !box_miss_f32_enter(nd.b1, r32, tmin32, tmax32, e1);
+                        h0 = h0 && !(node & SKIP_CHILD0) && (nd.c0 >> OREF_KIND_SHIFT) != OK_EMPTY;
+                        h1 = h1 && !(node & SKIP_CHILD1) && (nd.c1 >> OREF_KIND_SHIFT) != OK_EMPTY;
+                        const bool one_first = h1 && (!h0 || e1 < e0);
+                        if (h0 && h1) {
+                            const uint32_t far_slot = one_first ? 0u : 1u;
+                            const uint32_t far_ref = one_first ? nd.c0 : nd.c1;
+                            const uint32_t entry = (far_ref >> OREF_KIND_SHIFT) == OK_INNER ? far_ref : (S_TOP | (nid << 1) | far_slot);
+                            stack[sp * THREADS] = (StackT)entry;
+                            sp++;
+                        }
+                        o_next(h0 || h1, one_first ? nd.c1 : nd.c0);
                     }
-                    // NodeKind INNER / SPHERES / QUADS = 0 / 1 / 2 = Stage ST_BOX / ST_SPHERE / ST_QUAD
-                    const uint32_t hit_stage = (!HAS_OTHER || kind < 3u) ? kind : (uint32_t)ST_OTHER;
-                    const uint32_t hit_node = kind == NK_INNER ? node + 1u : (is_leaf ? nd.skip : node);
-                    node = miss ? nd.skip : hit_node;
-                    stage = miss ? (uint32_t)ST_BOX : hit_stage;
-                    if (stage == ST_BOX && node >= n_nodes) stage = ST_SHADE;
+                } else {
+                    if (stage == ST_BOX) {
+                        const NodeData nd = load_node<LDS>(P, lds_raw, node);
+                        if (COUNT) cn.node_visits += (nd.packed & N32_NO_BBOX) ? 0u : 1u;
+                        const bool miss = box_miss_f32(nd.lo, nd.hi, r32, tmin32, tmax32);
+                        // dispatch on the record kind, branch-free: INNER (0) walks on to the next record, a leaf (1, 2)
+                        // queues for its primitive stage and will continue at `skip`, anything else (>= 3) queues for ST_OTHER
+                        const uint32_t kind = nd.packed & N32_KIND_MASK;
+                        const uint32_t a_field = nd.packed >> N32_A_SHIFT;
+                        const bool is_leaf = kind == NK_SPHERES || kind == NK_QUADS;
+                        if (!miss && is_leaf) {
+                            prim_cur = a_field;
+                            prim_end = a_field + ((nd.packed >> N32_COUNT_SHIFT) & N32_COUNT_MASK);
+                        }
+                        // NodeKind INNER / SPHERES / QUADS = 0 / 1 / 2 = Stage ST_BOX / ST_SPHERE / ST_QUAD
+                        const uint32_t hit_stage = (!HAS_OTHER || kind < 3u) ? kind : (uint32_t)ST_OTHER;
+                        const uint32_t hit_node = kind == NK_INNER ? node + 1u : (is_leaf ? nd.skip : node);
+                        node = miss ? nd.skip : hit_node;
+                        stage = miss ? (uint32_t)ST_BOX : hit_stage;
+                        if (stage == ST_BOX && node >= n_nodes) stage = ST_SHADE;
+                    }
                 }
                 in_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
                 if (COUNT && in_box * 64u >= P.th_box * live && in_box > 0) { prof_rounds[ST_BOX] += 1; prof_lanes[ST_BOX] += in_box; }
@@ -457,18 +575,25 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 const uint32_t q = prim_cur;
                 const Sphere *s = &sphere_tab[q];
                 V3 center = ld3(s->center);
-                if (s->is_moving) center = center + ld3(s->center_vec) * time;
+                if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
                 const V3 oc = o - center;
                 const double half_b = dot(oc, d);
                 const double c = len2(oc) - s->radius * s->radius;
                 const double discriminant = half_b * half_b - a * c;
                 if (!(discriminant < 0.0)) {
                     const double sqrtd = __builtin_sqrt(discriminant);
+                    // Interval::surrounds (src/interval.rs:44-46); the ordered walk also settles ties (see wins_tie)
+                    auto inside = [&](double root) {
+                        if (cur_tmin < root && root < cur_tmax) return true;
+                        if constexpr (ORDERED)
+                            return cur_tmin < root && root == cur_tmax && best_prim != PRIM_NONE && wins_tie(s->seq_moving >> 1, false);
+                        return false;
+                    };
                     double root = (-half_b - sqrtd) / a;
-                    bool ok = cur_tmin < root && root < cur_tmax;
+                    bool ok = inside(root);
                     if (!ok) {
                         root = (-half_b + sqrtd) / a;
-                        ok = cur_tmin < root && root < cur_tmax;
+                        ok = inside(root);
                     }
                     if (ok) {
                         cur_tmax = root;
@@ -478,7 +603,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                 }
                 prim_cur = q + 1;
-                if (prim_cur >= prim_end) stage = node >= n_nodes ? ST_SHADE : ST_BOX;
+                if (prim_cur >= prim_end) {
+                    if constexpr (ORDERED) o_next(false, 0u);
+                    else stage = node >= n_nodes ? ST_SHADE : ST_BOX;
+                }
             }
         } else if (HAS_QUADS && run == ST_QUAD) {
             // ---------------- Quad::hit (src/quad.rs:96-127): all quads of the leaf (HittableList order) ----------------
@@ -490,7 +618,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const double denom = dot(normal, d);
                     if (__builtin_fabs(denom) < 1e-8) continue;
                     const double t = (qd->d - dot(normal, o)) / denom;
-                    if (!(cur_tmin <= t && t <= cur_tmax)) continue;
+                    if (!(cur_tmin <= t && t <= cur_tmax)) continue; // Interval::contains (src/interval.rs:40-42)
+                    if constexpr (ORDERED) // the ordered walk settles ties explicitly (see wins_tie)
+                        if (t == cur_tmax && best_prim != PRIM_NONE && !wins_tie(qd->seq, true)) continue;
                     const V3 intersection = o + d * t;
                     const V3 php = intersection - ld3(qd->q);
                     const V3 qw = ld3(qd->w);
@@ -503,10 +633,37 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     else mode |= 0x100u;
                 }
                 prim_cur = prim_end;
-                stage = node >= n_nodes ? ST_SHADE : ST_BOX;
+                if constexpr (ORDERED) o_next(false, 0u);
+                else stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
         } else if (HAS_OTHER && run == ST_OTHER) {
             // ---------------- frame changes and ConstantMedium steps ----------------
+            if constexpr (ORDERED) {
+                if (stage == ST_OTHER) { // enter the frame of instance `node`, or leave the current one
+                    const bool leaving = node == NODE_FRAME_EXIT;
+                    const size_t ws = P.n_threads;
+                    if (leaving) {
+                        cur_inst = P.insts[cur_inst].parent;
+                        o = v3(world_slot[0], world_slot[ws], world_slot[2 * ws]);
+                        d = v3(world_slot[3 * ws], world_slot[4 * ws], world_slot[5 * ws]);
+                        ray_to_frame(P.insts, cur_inst, o, d);
+                    } else {
+                        if (COUNT) cn.instance_enters++;
+                        if (cur_inst < 0) { // leaving the world frame: park the world ray
+                            world_slot[0] = o.x; world_slot[ws] = o.y; world_slot[2 * ws] = o.z;
+                            world_slot[3 * ws] = d.x; world_slot[4 * ws] = d.y; world_slot[5 * ws] = d.z;
+                        }
+                        apply_instance(P.insts[node], o, d);
+                        cur_inst = (int32_t)node;
+                        stack[sp * THREADS] = (StackT)S_EXIT;
+                        sp++;
+                    }
+                    refresh_ray32();
+                    a = len2(d);
+                    if (leaving) o_next(false, 0u);
+                    else { node = P.insts[cur_inst].root; stage = ST_BOX; }
+                }
+            } else
             if (stage == ST_OTHER) {
                 const NodeData nd = load_node<LDS>(P, lds_raw, node);
                 const uint32_t kind = nd.packed & N32_KIND_MASK;
@@ -541,7 +698,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const Medium md = P.media[na];
                     const Sphere *s = &sphere_tab[md.first_node];
                     V3 center = ld3(s->center);
-                    if (s->is_moving) center = center + ld3(s->center_vec) * time;
+                    if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
                     const V3 oc = o - center;
                     const double half_b = dot(oc, d);
                     const double c = len2(oc) - s->radius * s->radius;
@@ -647,7 +804,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (HAS_SPHERES && (pk == PRIM_SPHERE || (!HAS_QUADS && !HAS_MEDIA))) { // src/sphere.rs:85-88
                         const Sphere *s = &sphere_tab[pi];
                         V3 center = ld3(s->center);
-                        if (s->is_moving) center = center + ld3(s->center_vec) * time;
+                        if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
                         outward_normal = div(p - center, s->radius);
                         mat = s->material;
                         uv_from_sphere = true;
@@ -827,7 +984,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 refresh_interval32();
                 best_t = INF; best_prim = PRIM_NONE; best_inst = -1; cur_inst = -1;
                 mode = 0;
-                node = 0;
+                node = first_node;
+                sp = 0;
                 stage = ST_BOX;
             }
         }
@@ -1008,12 +1166,19 @@ struct Tuning {
     int forced[4] = {-1, -1, -1, -1};        // prim, other, shade, box
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     int refit = 1;   // 0: walk the reference's own (looser) boxes
+    int ordered = 1; // 0: always walk the threaded records in the reference's order (scenes created afterwards)
+    OrderedOptions ordered_options;
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
         auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
         env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]);
         if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
         if (const char *e = getenv("RT_REFIT")) refit = atoi(e);
+        if (const char *e = getenv("RT_ORDERED")) ordered = atoi(e);
+        if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
+        if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
+        if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
+        if (const char *e = getenv("RT_SAH_INSTANCE")) ordered_options.cost_instance = atof(e);
         if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
     }
     Thresholds pick(const Thresholds &preset) const {
@@ -1056,6 +1221,9 @@ struct rt_scene {
     DeviceArray<uint8_t> texels;
     DeviceArray<double> lut;
     uint32_t n_nodes = 0;
+    bool ordered = false;                        // ordered layout (rt_ordered.hpp): onodes instead of nodes
+    DeviceArray<ONode> onodes;
+    uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
     rt_scene_stats stats{};
     std::mutex mu;
     std::map<hipStream_t, Workspace> workspaces; // one per stream: launches on a stream are ordered
@@ -1075,25 +1243,40 @@ constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 // ones for scenes that fit the LDS entirely and use a subset of the features (BASELINE configs 1/2 and 3).
 constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
 constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
-uint32_t kernel_features_for(uint32_t scene_features, int lds) {
+constexpr uint32_t FEAT_NO_MEDIA = F_ALL & ~F_MEDIA;       // the ordered walk's general kernel
+uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
     if (lds == 3 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
     if (lds == 3 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
-    return F_ALL;
+    return ordered ? FEAT_NO_MEDIA : F_ALL;
 }
-const void *kernel_for(int lds, bool counted, uint32_t feat) {
-#define RT_PICK(L, T, F) (counted ? (const void *)path_kernel<true, L, T, F> : (const void *)path_kernel<false, L, T, F>)
-    if (lds == 3) {
-        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID);
-        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES);
-        return RT_PICK(3, LDS_THREADS, F_ALL);
+const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered) {
+#define RT_PICK(L, T, F, O) (counted ? (const void *)path_kernel<true, L, T, F, O> : (const void *)path_kernel<false, L, T, F, O>)
+    if (ordered) {
+        if (lds == 3) {
+            if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true);
+            if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true);
+            return RT_PICK(3, LDS_THREADS, FEAT_NO_MEDIA, true);
+        }
+        if (lds == 1) return RT_PICK(1, LDS_THREADS, FEAT_NO_MEDIA, true);
+        return RT_PICK(0, GLOBAL_THREADS, FEAT_NO_MEDIA, true);
     }
-    if (lds == 2) return RT_PICK(2, LDS_THREADS, F_ALL);
-    if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL);
-    return RT_PICK(0, GLOBAL_THREADS, F_ALL);
+    if (lds == 3) {
+        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false);
+        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, false);
+        return RT_PICK(3, LDS_THREADS, F_ALL, false);
+    }
+    if (lds == 2) return RT_PICK(2, LDS_THREADS, F_ALL, false);
+    if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL, false);
+    return RT_PICK(0, GLOBAL_THREADS, F_ALL, false);
 #undef RT_PICK
 }
 uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return s->lds_prefix_bytes[lds]; }
-size_t dynamic_lds_bytes(const rt_scene *s, int lds) { return lds_image_bytes_for(s, lds); }
+// the LDS image, then (ordered walk) the per-lane stacks: 2-byte entries beside an LDS-resident scene, else 4-byte
+size_t stack_bytes(const rt_scene *s, int lds) {
+    if (!s->ordered) return 0;
+    return (size_t)s->o_stack * (lds ? (size_t)LDS_THREADS * 2u : (size_t)GLOBAL_THREADS * 4u);
+}
+size_t dynamic_lds_bytes(const rt_scene *s, int lds) { return lds_image_bytes_for(s, lds) + stack_bytes(s, lds); }
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
     dst.bytes = src.size() * sizeof(T);
@@ -1125,7 +1308,7 @@ void free_scene(rt_scene *s) {
     }
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
-    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->onodes.ptr);
     delete s;
 }
 
@@ -1238,8 +1421,9 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
+    K.onodes = scene->onodes.ptr; K.o_root = scene->o_root; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     {
-        const uint32_t kf = kernel_features_for(scene->features, lds);
+        const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
         const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : tn.general));
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box;
     }
@@ -1254,7 +1438,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
         {
             void *args[] = {(void *)&K};
-            HIP_TRY(hipLaunchKernel(kernel_for(lds, counted, kernel_features_for(scene->features, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
+            HIP_TRY(hipLaunchKernel(kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
         }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(256), 0, stream, K);
@@ -1305,6 +1489,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, tuning().refit != 0);
+        if (tuning().ordered) build_ordered(cs, tuning().ordered_options);
     } catch (const CompileError &e) {
         return fail(e.status, e.what());
     } catch (const std::exception &e) {
@@ -1325,23 +1510,29 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
                   (cs.media.empty() ? 0u : F_MEDIA);
     for (const auto &t : cs.textures)
         if (t.kind != RT_TEXTURE_SOLID) s->features |= F_TEXTURES;
-    // LDS image (see load_node): the two halves of the node records as separate tables, then spheres and quads
+    s->ordered = cs.ordered;
+    s->o_root = cs.ordered_root;
+    s->o_stack = cs.ordered_stack;
+    // LDS image (see load_node / load_onode): the 16-byte parts of the records as separate tables, then spheres and quads
     {
-        const size_t n = cs.nodes32.size();
-        const size_t off_b = n * 16, off_sph = n * 32;
+        const size_t n = cs.ordered ? cs.onodes.size() : cs.nodes32.size();
+        const size_t parts = cs.ordered ? 4 : 2;
+        const size_t off_b = n * 16, off_sph = n * 16 * parts;
         const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
         const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
+        const size_t stack = stack_bytes(s, 1);
         // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
-        s->lds_level = total <= LDS_BUDGET_BYTES ? 3 : (off_sph <= LDS_BUDGET_BYTES ? 1 : 0);
+        s->lds_level = total + stack <= LDS_BUDGET_BYTES ? 3 : (off_sph + stack <= LDS_BUDGET_BYTES ? 1 : 0);
+        if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries hold (record << 1 | slot) in 15 bits
         if (s->lds_level) {
             // every level copies a prefix of the same image: node tables | spheres | quads
             const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
             std::vector<uint4> img(used / 16);
             unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
-            for (size_t i = 0; i < n; ++i) {
-                memcpy(base + i * 16, &cs.nodes32[i], 16);
-                memcpy(base + off_b + i * 16, reinterpret_cast<const unsigned char *>(&cs.nodes32[i]) + 16, 16);
-            }
+            const unsigned char *src = cs.ordered ? reinterpret_cast<const unsigned char *>(cs.onodes.data())
+                                                  : reinterpret_cast<const unsigned char *>(cs.nodes32.data());
+            for (size_t i = 0; i < n; ++i)
+                for (size_t q = 0; q < parts; ++q) memcpy(base + q * off_b + i * 16, src + (i * parts + q) * 16, 16);
             if (s->lds_level >= 2 && !cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
             if (s->lds_level == 3 && !cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
             int urc = upload(s->lds_image, img);
@@ -1358,7 +1549,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     for (int lds = 0; lds < 4; ++lds)
         for (int counted = 0; counted < 2; ++counted) {
             if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
-            const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds));
+            const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered);
             const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
             const size_t dyn = dynamic_lds_bytes(s, lds);
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
@@ -1381,7 +1572,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     }
 
     int rc = RT_OK;
-    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
+    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->onodes, cs.onodes)) != RT_OK ||
+        (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
         (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
         (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
         (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
@@ -1392,13 +1584,14 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     }
     s->n_nodes = (uint32_t)cs.nodes.size();
     rt_scene_stats &st = s->stats;
-    st.node_bytes = s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
+    st.node_bytes = cs.ordered ? s->onodes.bytes : s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
     st.instance_bytes = s->insts.bytes; st.medium_bytes = s->media.bytes; st.material_bytes = s->mats.bytes;
     st.texture_bytes = s->texs.bytes; st.perlin_bytes = s->perlins.bytes; st.image_bytes = s->texels.bytes;
-    st.n_nodes = (uint32_t)cs.nodes.size(); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
+    st.n_nodes = (uint32_t)(cs.ordered ? cs.onodes.size() : cs.nodes.size()); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
     st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
     st.max_instance_depth = cs.max_instance_depth;
-    st.lds_nodes = s->lds_level ? (uint32_t)cs.nodes.size() : 0; st.lds_bytes = s->lds_level ? s->lds_image_bytes : 0;
+    st.lds_nodes = s->lds_level ? st.n_nodes : 0; st.lds_bytes = s->lds_level ? (uint32_t)dynamic_lds_bytes(s, s->lds_level) : 0;
+    st.ordered = cs.ordered ? 1u : 0u; st.stack_entries = cs.ordered ? cs.ordered_stack : 0u;
     *out_scene = s;
     return RT_OK;
 }
@@ -1498,6 +1691,63 @@ int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int
     return RT_OK;
 }
 
+int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max) {
+    Tuning &t = tuning();
+    if (ordered >= 0) t.ordered = ordered;
+    if (leaf_max > 0) t.ordered_options.leaf_max = (uint32_t)leaf_max < OREF_MAX_LEAF ? (uint32_t)leaf_max : OREF_MAX_LEAF;
+    return RT_OK;
+}
+
+int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) {
+    if (!desc || !io) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: null argument");
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc, true);
+        build_ordered(cs, tuning().ordered_options);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_ordered_layout: ") + e.what());
+    }
+    io->ordered = cs.ordered ? 1u : 0u;
+    io->root = cs.ordered_root;
+    io->stack_entries = cs.ordered_stack;
+    io->n_nodes = (int64_t)cs.onodes.size(); io->n_spheres = (int64_t)cs.spheres.size();
+    io->n_quads = (int64_t)cs.quads.size(); io->n_instances = (int64_t)cs.instances.size();
+    if (io->nodes) {
+        if (io->cap_nodes < io->n_nodes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: nodes buffer too small");
+        if (io->n_nodes) memcpy(io->nodes, cs.onodes.data(), cs.onodes.size() * sizeof(ONode));
+    }
+    if (io->spheres) {
+        if (io->cap_spheres < io->n_spheres) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: spheres buffer too small");
+        for (size_t i = 0; i < cs.spheres.size(); ++i) {
+            const Sphere &sp = cs.spheres[i];
+            double *o = io->spheres + i * 9;
+            for (int k = 0; k < 3; ++k) { o[k] = sp.center[k]; o[4 + k] = sp.center_vec[k]; }
+            o[3] = sp.radius; o[7] = (double)(sp.seq_moving >> 1); o[8] = (double)(sp.seq_moving & 1u);
+        }
+    }
+    if (io->quads) {
+        if (io->cap_quads < io->n_quads) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: quads buffer too small");
+        for (size_t i = 0; i < cs.quads.size(); ++i) {
+            const Quad &qd = cs.quads[i];
+            double *o = io->quads + i * 10;
+            for (int k = 0; k < 3; ++k) { o[k] = qd.q[k]; o[3 + k] = qd.u[k]; o[6 + k] = qd.v[k]; }
+            o[9] = (double)qd.seq;
+        }
+    }
+    if (io->instances) {
+        if (io->cap_instances < io->n_instances) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: instances buffer too small");
+        for (size_t i = 0; i < cs.instances.size(); ++i) {
+            const Instance &in = cs.instances[i];
+            double *o = io->instances + i * 8;
+            for (int k = 0; k < 3; ++k) o[k] = in.offset[k];
+            o[3] = in.sin_theta; o[4] = in.cos_theta; o[5] = (double)in.parent; o[6] = (double)in.flags; o[7] = (double)in.root;
+        }
+    }
+    return RT_OK;
+}
+
 int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity, int64_t *out_count) {
     if (!desc || !out_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: null argument");
     CompiledScene cs;
@@ -1529,7 +1779,7 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
             const uint32_t first = o.kind == NK_SPHERES ? n.a : cs.media[n.a].first_node, count = o.kind == NK_SPHERES ? n.b : 1u;
             for (uint32_t q = first; q < first + count; ++q) {
                 const Sphere &sp = cs.spheres[q];
-                for (int e = 0; e < (sp.is_moving ? 2 : 1); ++e) {
+                for (int e = 0; e < ((sp.seq_moving & 1u) ? 2 : 1); ++e) {
                     const double c[3] = {sp.center[0] + e * sp.center_vec[0], sp.center[1] + e * sp.center_vec[1], sp.center[2] + e * sp.center_vec[2]};
                     grow(c[0] - sp.radius, c[1] - sp.radius, c[2] - sp.radius);
                     grow(c[0] + sp.radius, c[1] + sp.radius, c[2] + sp.radius);

@@ -50,13 +50,31 @@ static_assert(sizeof(Node32) == 32, "Node32 must be 32 bytes");
 constexpr uint32_t N32_KIND_MASK = 0xfu, N32_NO_BBOX = 0x10u, N32_COUNT_SHIFT = 5, N32_COUNT_MASK = 0x7fu, N32_A_SHIFT = 12;
 constexpr uint32_t N32_MAX_COUNT = 127, N32_MAX_A = (1u << 20) - 1u;
 
+// ---- ordered layout (closest-hit queries whose result does not depend on the visiting order) ---------------
+// A scene without a ConstantMedium consumes no random numbers inside hit(): the closest hit is then a pure
+// minimum over the primitives (ties settled by the reference's scan order, rt_kernel.hip "ties"), so any tree
+// and any visiting order give the reference's result.  For those scenes the compiler builds its own SAH tree
+// per frame (world, and one per Translate/RotateY instance) and the kernel walks it nearest child first with
+// a short per-lane stack.  One record = one inner node holding BOTH children's boxes and references.
+enum OrderedKind : uint32_t { OK_INNER = 0, OK_SPHERES = 1, OK_QUADS = 2, OK_INSTANCE = 3, OK_EMPTY = 7 };
+constexpr uint32_t OREF_KIND_SHIFT = 29, OREF_COUNT_SHIFT = 26, OREF_COUNT_MASK = 7u, OREF_INDEX_MASK = (1u << 26) - 1u;
+constexpr uint32_t OREF_MAX_LEAF = 8;
+struct alignas(64) ONode {
+    float b0[6]; // child 0: x.lo, x.hi, y.lo, y.hi, z.lo, z.hi (f32, rounded outward)
+    float b1[6]; // child 1
+    uint32_t c[2]; // kind (3 bits) | count - 1 (3 bits) | index (26 bits): inner record / first primitive / instance
+    uint32_t _pad[2];
+};
+static_assert(sizeof(ONode) == 64, "ONode must be 64 bytes");
+constexpr uint32_t ORDERED_MAX_STACK = 32; // per-lane stack entries the kernel provides at most
+
 // 64 bytes
 struct alignas(64) Sphere {
     double center[3];
     double radius;
     double center_vec[3];
     uint32_t material;
-    uint32_t is_moving;
+    uint32_t seq_moving; // bit 0: the sphere moves; bits 1..31: seq, the primitive's position in the reference's scan order
 };
 static_assert(sizeof(Sphere) == 64, "Sphere must be 64 bytes");
 
@@ -69,7 +87,8 @@ struct alignas(16) Quad {
     double u[3];
     double v[3];
     uint32_t material;
-    uint32_t _pad[3];
+    uint32_t seq; // the primitive's position in the reference's scan order (spheres and quads share one numbering)
+    uint32_t _pad[2];
 };
 static_assert(sizeof(Quad) == 144, "Quad must be 144 bytes");
 
@@ -81,7 +100,8 @@ struct alignas(64) Instance {
     int32_t parent;
     uint32_t flags; // bit 0: has translate, bit 1: has rotate
     uint32_t depth; // 0 for an instance in the world frame
-    uint32_t _pad[3];
+    uint32_t root;  // ordered layout: the root record of the tree over this frame's contents
+    uint32_t _pad[2];
 };
 static_assert(sizeof(Instance) == 64, "Instance must be 64 bytes");
 constexpr uint32_t INST_TRANSLATE = 1u, INST_ROTATE = 2u;

@@ -1,0 +1,284 @@
+// Ordered layout builder: CompiledScene (threaded records + primitive tables) -> one SAH tree per frame
+// (rt_layout.h "ordered layout").  Host code, no HIP.
+//
+// Why the kernel may walk a tree of its own: in a scene without a ConstantMedium, hit() draws no random number
+// and `world.hit(r, (0.001, inf))` (src/renderer.rs:144) is a pure minimum over the primitives — BVHNode /
+// HittableList only decide which tests are skipped (src/bvh.rs:97-108, src/hittable.rs:61-74).  The reference's
+// tree (random axis, median split, src/bvh.rs:31-66) must be walked left child first to reproduce its tie
+// handling; with ties settled explicitly by `seq` (rt_kernel.hip "ties") neither the tree nor the order matters,
+// and a surface-area-heuristic tree walked nearest child first needs a fraction of the box tests.
+// A ConstantMedium breaks this (its hit() consumes a draw only if the walk reaches it, src/constant_medium.rs:33-61):
+// such scenes keep the threaded layout.
+#pragma once
+#include "rt_compile.hpp"
+#include <algorithm>
+#include <numeric>
+
+namespace rtd {
+
+struct OrderedOptions {
+    uint32_t leaf_max = 4;        // primitives per leaf at most (<= OREF_MAX_LEAF)
+    double cost_node = 1.0;       // one record visit (two box tests) ...
+    double cost_sphere = 1.6;     // ... against one Sphere::hit,
+    double cost_quad = 0.8;       // one Quad::hit (most end at the plane test),
+    double cost_instance = 6.0;   // and one frame change plus the walk inside
+    uint32_t world_depth = 22;    // inner records on a root-to-leaf path at most: world frame
+    uint32_t frame_depth = 8;     // ... and inside a frame (the kernel's stack holds ORDERED_MAX_STACK entries in all)
+};
+
+class OrderedBuilder {
+  public:
+    OrderedBuilder(CompiledScene &cs, const OrderedOptions &opt) : cs_(cs), opt_(opt) {}
+
+    // false: the scene must keep the threaded layout (a medium, or a tree too deep for the stack)
+    bool run() {
+        if (!cs_.media.empty()) return false;
+        if (cs_.spheres.size() > OREF_INDEX_MASK || cs_.quads.size() > OREF_INDEX_MASK) return false;
+        if (!collect()) return false;
+        const size_t n_inst = cs_.instances.size();
+        need_.assign(n_inst + 1, 0);
+        bound_.assign(n_inst + 1, Bound());
+        root_.assign(n_inst + 1, 0);
+        // innermost frames first: an instance's box in its parent's frame comes from the tree built for it
+        for (size_t f = n_inst + 1; f-- > 0;) {
+            std::vector<Item> &items = frames_[f];
+            for (Item &it : items)
+                if (it.kind == OK_INSTANCE) {
+                    Bound b = instance_bound(cs_.instances[it.index], bound_[it.index + 1]);
+                    if (!b.empty())
+                        for (int ax = 0; ax < 3; ++ax) pad_axis(b.lo[ax], b.hi[ax]);
+                    it.b = b;
+                }
+            // geometry-free instances (an empty list inside a Translate) can never be hit: drop them
+            items.erase(std::remove_if(items.begin(), items.end(), [](const Item &it) { return it.b.empty(); }), items.end());
+            for (Item &it : items) {
+                for (int ax = 0; ax < 3; ++ax) it.c[ax] = 0.5 * (it.b.lo[ax] + it.b.hi[ax]);
+                bound_[f].add(it.b);
+            }
+            build_frame(f);
+        }
+        if (need_[0] > ORDERED_MAX_STACK) return false;
+        for (size_t i = 0; i < n_inst; ++i) cs_.instances[i].root = root_[i + 1];
+        cs_.spheres.swap(new_spheres_);
+        cs_.quads.swap(new_quads_);
+        cs_.onodes.swap(nodes_);
+        cs_.ordered_root = root_[0];
+        cs_.ordered_stack = need_[0] ? need_[0] : 1u;
+        cs_.ordered = true;
+        return true;
+    }
+
+  private:
+    struct Item {
+        Bound b;
+        double c[3];
+        uint32_t kind;  // OK_SPHERES / OK_QUADS / OK_INSTANCE
+        uint32_t index; // in cs_.spheres / cs_.quads / cs_.instances
+        uint32_t seq;
+    };
+    struct Built {
+        uint32_t ref;
+        Bound b;
+        uint32_t need; // stack entries a walk below this child can hold at once
+    };
+
+    CompiledScene &cs_;
+    OrderedOptions opt_;
+    std::vector<std::vector<Item>> frames_; // [0] world, [1 + i] instance i
+    std::vector<uint32_t> need_, root_;
+    std::vector<Bound> bound_;
+    std::vector<ONode> nodes_;
+    std::vector<Sphere> new_spheres_;
+    std::vector<Quad> new_quads_;
+
+    // the threaded records list every primitive and frame change in the reference's scan order
+    bool collect() {
+        frames_.assign(cs_.instances.size() + 1, {});
+        std::vector<uint32_t> open{0u};
+        for (const Node &n : cs_.nodes) {
+            const uint32_t kind = n.kind & NODE_KIND_MASK;
+            std::vector<Item> &cur = frames_[open.back()];
+            if (kind == NK_SPHERES || kind == NK_QUADS) {
+                for (uint32_t i = 0; i < n.b; ++i) {
+                    Item it{};
+                    it.kind = kind == NK_SPHERES ? OK_SPHERES : OK_QUADS;
+                    it.index = n.a + i;
+                    it.b = kind == NK_SPHERES ? sphere_bound(cs_.spheres[it.index]) : quad_bound(cs_.quads[it.index]);
+                    it.seq = kind == NK_SPHERES ? cs_.spheres[it.index].seq_moving >> 1 : cs_.quads[it.index].seq;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (!std::isfinite(it.b.lo[ax]) || !std::isfinite(it.b.hi[ax])) return false; // not a shape a box can hold
+                        pad_axis(it.b.lo[ax], it.b.hi[ax]);
+                    }
+                    cur.push_back(it);
+                }
+            } else if (kind == NK_INST_ENTER) {
+                Item it{};
+                it.kind = OK_INSTANCE;
+                it.index = n.a;
+                cur.push_back(it);
+                open.push_back(n.a + 1u);
+            } else if (kind == NK_INST_EXIT) {
+                open.pop_back();
+            } else if (kind != NK_INNER) {
+                return false;
+            }
+        }
+        return true;
+    }
+
+    double item_cost(const Item &it) const {
+        return it.kind == OK_SPHERES ? opt_.cost_sphere : (it.kind == OK_QUADS ? opt_.cost_quad : opt_.cost_instance);
+    }
+    static double half_area(const Bound &b) {
+        if (b.empty()) return 0.0;
+        const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+        return x * y + y * z + z * x;
+    }
+    static uint32_t levels_for(size_t n) { // inner records on a path when n single-item leaves are split evenly
+        uint32_t l = 0;
+        while (((size_t)1 << l) < n) ++l;
+        return l;
+    }
+
+    uint32_t alloc_node() {
+        ONode n{};
+        n.c[0] = n.c[1] = OK_EMPTY << OREF_KIND_SHIFT;
+        nodes_.push_back(n);
+        return (uint32_t)nodes_.size() - 1u;
+    }
+    static void set_child(ONode &n, int slot, const Built &c) {
+        float *b = slot ? n.b1 : n.b0;
+        for (int ax = 0; ax < 3; ++ax) {
+            b[2 * ax] = round_down(c.b.lo[ax]);
+            b[2 * ax + 1] = round_up(c.b.hi[ax]);
+        }
+        n.c[slot] = c.ref;
+    }
+
+    void build_frame(size_t f) {
+        std::vector<Item> &items = frames_[f];
+        const uint32_t budget = f == 0 ? opt_.world_depth : opt_.frame_depth;
+        if (items.empty()) { // nothing to hit: a record with two empty children
+            root_[f] = alloc_node();
+            need_[f] = 1;
+            return;
+        }
+        if (levels_for(items.size()) > budget) { need_[f] = ORDERED_MAX_STACK + 1; return; }
+        Built r = build(items, 0, items.size(), budget);
+        if ((r.ref >> OREF_KIND_SHIFT) != OK_INNER) { // a frame's root is always a record
+            const uint32_t id = alloc_node();
+            set_child(nodes_[id], 0, r);
+            r.ref = id;
+            r.need += 1;
+        }
+        root_[f] = r.ref;
+        need_[f] = r.need;
+    }
+
+    Built make_leaf(std::vector<Item> &items, size_t lo, size_t hi) {
+        Built out{};
+        for (size_t i = lo; i < hi; ++i) out.b.add(items[i].b);
+        const Item &first = items[lo];
+        if (first.kind == OK_INSTANCE) {
+            out.ref = (OK_INSTANCE << OREF_KIND_SHIFT) | first.index;
+            out.need = 1u + need_[first.index + 1]; // the frame-exit marker, then the walk inside
+            return out;
+        }
+        // primitives of a leaf sit next to each other in the table, in scan order
+        std::sort(items.begin() + (ptrdiff_t)lo, items.begin() + (ptrdiff_t)hi, [](const Item &a, const Item &b) { return a.seq < b.seq; });
+        uint32_t start;
+        if (first.kind == OK_SPHERES) {
+            start = (uint32_t)new_spheres_.size();
+            for (size_t i = lo; i < hi; ++i) new_spheres_.push_back(cs_.spheres[items[i].index]);
+        } else {
+            start = (uint32_t)new_quads_.size();
+            for (size_t i = lo; i < hi; ++i) new_quads_.push_back(cs_.quads[items[i].index]);
+        }
+        out.ref = (first.kind << OREF_KIND_SHIFT) | ((uint32_t)(hi - lo - 1) << OREF_COUNT_SHIFT) | start;
+        out.need = 0;
+        return out;
+    }
+
+    // SAH split of items [lo, hi): returns the position to cut at after reordering the range, or lo if none was found
+    size_t sah_split(std::vector<Item> &items, size_t lo, size_t hi, double &best_cost) {
+        const size_t n = hi - lo;
+        Bound all;
+        for (size_t i = lo; i < hi; ++i) all.add(items[i].b);
+        const double inv_area = 1.0 / std::fmax(half_area(all), 1e-300);
+        best_cost = INFINITY;
+        int best_axis = -1;
+        size_t best_cut = 0;
+        std::vector<double> right_area(n), right_cost(n);
+        std::vector<uint32_t> order(n);
+        for (int ax = 0; ax < 3; ++ax) {
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return items[lo + a].c[ax] < items[lo + b].c[ax]; });
+            Bound acc;
+            double cost = 0.0;
+            for (size_t k = n; k-- > 0;) {
+                acc.add(items[lo + order[k]].b);
+                cost += item_cost(items[lo + order[k]]);
+                right_area[k] = half_area(acc);
+                right_cost[k] = cost;
+            }
+            acc = Bound();
+            cost = 0.0;
+            for (size_t k = 0; k + 1 < n; ++k) { // cut after position k
+                acc.add(items[lo + order[k]].b);
+                cost += item_cost(items[lo + order[k]]);
+                const double c = opt_.cost_node + (half_area(acc) * cost + right_area[k + 1] * right_cost[k + 1]) * inv_area;
+                if (c < best_cost) { best_cost = c; best_axis = ax; best_cut = k + 1; }
+            }
+        }
+        if (best_axis < 0) return lo;
+        const int ax = best_axis; // the same stable sort again: the order the cut was found in
+        std::stable_sort(items.begin() + (ptrdiff_t)lo, items.begin() + (ptrdiff_t)hi, [ax](const Item &a, const Item &b) { return a.c[ax] < b.c[ax]; });
+        return lo + best_cut;
+    }
+    // even split along the widest axis of the centroids: what is left when the depth budget is nearly used up
+    size_t median_split(std::vector<Item> &items, size_t lo, size_t hi) {
+        double cl[3] = {INFINITY, INFINITY, INFINITY}, ch[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = lo; i < hi; ++i)
+            for (int ax = 0; ax < 3; ++ax) { cl[ax] = std::fmin(cl[ax], items[i].c[ax]); ch[ax] = std::fmax(ch[ax], items[i].c[ax]); }
+        int ax = 0;
+        if (ch[1] - cl[1] > ch[ax] - cl[ax]) ax = 1;
+        if (ch[2] - cl[2] > ch[ax] - cl[ax]) ax = 2;
+        std::stable_sort(items.begin() + (ptrdiff_t)lo, items.begin() + (ptrdiff_t)hi, [ax](const Item &a, const Item &b) { return a.c[ax] < b.c[ax]; });
+        return lo + (hi - lo + 1) / 2;
+    }
+
+    Built build(std::vector<Item> &items, size_t lo, size_t hi, uint32_t budget) {
+        const size_t n = hi - lo;
+        if (n == 1) return make_leaf(items, lo, hi);
+        bool can_leaf = n <= opt_.leaf_max && n <= OREF_MAX_LEAF && items[lo].kind != OK_INSTANCE;
+        double leaf_cost = 0.0;
+        for (size_t i = lo; i < hi; ++i) {
+            can_leaf = can_leaf && items[i].kind == items[lo].kind;
+            leaf_cost += item_cost(items[i]);
+        }
+        size_t cut = lo;
+        if (budget > levels_for(n)) {
+            double split_cost;
+            cut = sah_split(items, lo, hi, split_cost);
+            if (can_leaf && (cut == lo || leaf_cost <= split_cost)) return make_leaf(items, lo, hi);
+        } else if (can_leaf) {
+            return make_leaf(items, lo, hi);
+        }
+        if (cut == lo) cut = median_split(items, lo, hi);
+        const uint32_t id = alloc_node();
+        const Built l = build(items, lo, cut, budget - 1);
+        const Built r = build(items, cut, hi, budget - 1);
+        set_child(nodes_[id], 0, l);
+        set_child(nodes_[id], 1, r);
+        Built out{};
+        out.ref = id; // OK_INNER << 29 == 0
+        out.b = l.b;
+        out.b.add(r.b);
+        out.need = 1u + std::max(l.need, r.need);
+        return out;
+    }
+};
+
+inline bool build_ordered(CompiledScene &cs, const OrderedOptions &opt = OrderedOptions()) { return OrderedBuilder(cs, opt).run(); }
+
+} // namespace rtd

@@ -1,0 +1,142 @@
+"""Hand-made rt_scene_desc graphs for cases the reference's nine scenes never produce: primitives hit at exactly
+the same t (coincident copies, overlapping coplanar quads), single-primitive worlds, empty frames.
+
+A CustomScene quacks like rt.HostScene (desc, camera, width, height) for rt.DeviceScene and the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import math
+
+rt = importlib.import_module("rust-tracing_amd")
+
+
+def _v(x, y, z):
+    return rt.Vec3(float(x), float(y), float(z))
+
+
+class CustomScene:
+    def __init__(self, camera_from: "rt.HostScene", spp=4, depth=6, background=None):
+        self.spheres, self.quads, self.lists, self.items = [], [], [], []
+        self.translates, self.rotates, self.materials, self.textures = [], [], [], []
+        self.camera = rt.Camera.from_buffer_copy(camera_from.camera)
+        self.camera.samples_per_pixel = spp
+        self.camera.max_depth = depth
+        if background is not None:
+            self.camera.background = _v(*background)
+        self.desc = None
+
+    width = property(lambda self: self.camera.image_width)
+    height = property(lambda self: self.camera.image_height)
+
+    # ---- materials ----
+    def solid(self, r, g, b):
+        self.textures.append(rt.Texture(kind=rt.RT_TEXTURE_SOLID, even=-1, odd=-1, image=-1, perlin=-1, color=_v(r, g, b)))
+        return len(self.textures) - 1
+
+    def lambertian(self, r, g, b):
+        self.materials.append(rt.Material(kind=rt.RT_MATERIAL_LAMBERTIAN, texture=self.solid(r, g, b)))
+        return len(self.materials) - 1
+
+    def light(self, r, g, b):
+        self.materials.append(rt.Material(kind=rt.RT_MATERIAL_DIFFUSE_LIGHT, texture=self.solid(r, g, b)))
+        return len(self.materials) - 1
+
+    def metal(self, r, g, b, fuzz):
+        self.materials.append(rt.Material(kind=rt.RT_MATERIAL_METAL, texture=-1, albedo=_v(r, g, b), fuzz=fuzz))
+        return len(self.materials) - 1
+
+    def dielectric(self, ir):
+        self.materials.append(rt.Material(kind=rt.RT_MATERIAL_DIELECTRIC, texture=-1, ir=ir))
+        return len(self.materials) - 1
+
+    # ---- hittables: each returns an rt.Ref ----
+    def sphere(self, center, radius, material):
+        self.spheres.append(rt.Sphere(center=_v(*center), radius=radius, center_vec=_v(0, 0, 0), is_moving=0, material=material))
+        return rt.Ref(rt.RT_HITTABLE_SPHERE, len(self.spheres) - 1)
+
+    def quad(self, q, u, v, material):
+        # Quad::new (src/quad.rs:23-43), in Python floats = f64, same operation order as the host mirror
+        n = (u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0])
+        n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2]
+        rl = 1.0 / math.sqrt(n2)
+        normal = (n[0] * rl, n[1] * rl, n[2] * rl)
+        d = normal[0] * q[0] + normal[1] * q[1] + normal[2] * q[2]
+        w = (n[0] / n2, n[1] / n2, n[2] / n2)
+        self.quads.append(rt.Quad(q=_v(*q), u=_v(*u), v=_v(*v), w=_v(*w), normal=_v(*normal), d=d, material=material))
+        return rt.Ref(rt.RT_HITTABLE_QUAD, len(self.quads) - 1)
+
+    def list(self, refs):
+        first = len(self.items)
+        self.items.extend(refs)
+        self.lists.append(rt.List(first, len(refs)))
+        return rt.Ref(rt.RT_HITTABLE_LIST, len(self.lists) - 1)
+
+    def translate(self, ref, offset):
+        self.translates.append(rt.Translate(object=ref, offset=_v(*offset)))
+        return rt.Ref(rt.RT_HITTABLE_TRANSLATE, len(self.translates) - 1)
+
+    def rotate_y(self, ref, degrees):
+        th = math.radians(degrees)
+        self.rotates.append(rt.RotateY(object=ref, sin_theta=math.sin(th), cos_theta=math.cos(th)))
+        return rt.Ref(rt.RT_HITTABLE_ROTATE_Y, len(self.rotates) - 1)
+
+    def finish(self, world: "rt.Ref"):
+        def arr(kind, values):
+            a = (kind * max(1, len(values)))(*values)
+            return a
+
+        self._keep = dict(spheres=arr(rt.Sphere, self.spheres), quads=arr(rt.Quad, self.quads), lists=arr(rt.List, self.lists),
+                          items=arr(rt.Ref, self.items), translates=arr(rt.Translate, self.translates),
+                          rotates=arr(rt.RotateY, self.rotates), materials=arr(rt.Material, self.materials),
+                          textures=arr(rt.Texture, self.textures))
+        k = self._keep
+        d = rt.SceneDesc()
+        d.abi_version = rt.RT_ABI_VERSION
+        d.world = world
+        d.n_spheres, d.spheres = len(self.spheres), k["spheres"]
+        d.n_quads, d.quads = len(self.quads), k["quads"]
+        d.n_lists, d.lists = len(self.lists), k["lists"]
+        d.n_list_items, d.list_items = len(self.items), k["items"]
+        d.n_translates, d.translates = len(self.translates), k["translates"]
+        d.n_rotates, d.rotates = len(self.rotates), k["rotates"]
+        d.n_materials, d.materials = len(self.materials), k["materials"]
+        d.n_textures, d.textures = len(self.textures), k["textures"]
+        self.desc = d
+        return self
+
+
+def tie_scene(camera_from, order=0):
+    """Every primitive has coincident copies with different materials, so every hit is an exact tie; `order` permutes the
+    scan order of the world list (the winner of a tie depends on it)."""
+    s = CustomScene(camera_from, spp=4, depth=6, background=(0.7, 0.8, 1.0))
+    red, green, blue, white = s.lambertian(0.9, 0.1, 0.1), s.lambertian(0.1, 0.9, 0.1), s.lambertian(0.1, 0.1, 0.9), s.lambertian(0.8, 0.8, 0.8)
+    mirror, glass, lamp = s.metal(0.8, 0.8, 0.3, 0.0), s.dielectric(1.5), s.light(4, 4, 4)
+    back = [s.quad((-3, -3, -2), (6, 0, 0), (0, 6, 0), m) for m in (red, green, blue)]       # three coincident walls
+    half = s.quad((0, -3, -2), (3, 0, 0), (0, 6, 0), mirror)                                  # coplanar, covers half of them
+    floor = [s.quad((-3, -3, -2), (6, 0, 0), (0, 0, 4), m) for m in (white, red)]
+    balls = [s.sphere((-1.2, -0.5, 0.0), 1.0, m) for m in (green, glass, mirror)]             # three coincident spheres
+    ball2 = [s.sphere((1.3, -1.0, 0.5), 0.8, m) for m in (glass, blue)]
+    top = [s.quad((-1, 2.9, -1), (2, 0, 0), (0, 0, 2), m) for m in (lamp, white)]             # a light and its opaque copy
+    cube = s.translate(s.rotate_y(s.list([s.quad((-0.5, -0.5, 0.5), (1, 0, 0), (0, 1, 0), m) for m in (blue, mirror)] +
+                                         [s.quad((-0.5, -0.5, -0.5), (0, 0, 1), (0, 1, 0), m) for m in (red, green)] +
+                                         [s.sphere((0, 0, 0), 0.6, m) for m in (white, lamp)]), 30.0), (0.4, 1.2, 0.8))
+    items = back + [half] + floor + balls + ball2 + top + [cube]
+    if order == 1:
+        items = items[::-1]
+    elif order == 2:
+        items = items[1::2] + items[0::2]
+    return s.finish(s.list(items))
+
+
+def single_sphere_scene(camera_from):
+    s = CustomScene(camera_from, spp=4, depth=6, background=(0.7, 0.8, 1.0))
+    return s.finish(s.sphere((0, 0, 0), 2.0, s.lambertian(0.5, 0.6, 0.7)))
+
+
+def empty_frame_scene(camera_from):
+    """A Translate around an empty list next to real geometry: the frame can never be hit."""
+    s = CustomScene(camera_from, spp=4, depth=6, background=(0.7, 0.8, 1.0))
+    nothing = s.translate(s.list([]), (1, 0, 0))
+    return s.finish(s.list([nothing, s.sphere((0, 0, 0), 1.5, s.metal(0.7, 0.7, 0.7, 0.1)),
+                            s.quad((-3, -2, -3), (6, 0, 0), (0, 0, 6), s.lambertian(0.3, 0.7, 0.3))]))

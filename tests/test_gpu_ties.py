@@ -1,0 +1,50 @@
+"""GPU parity on hand-made scenes (tests/custom_scenes.py): exact ties, single primitives, empty frames — in both
+traversal modes (the library's own trees walked nearest child first / the reference's tree in the reference's order)."""
+import numpy as np
+import pytest
+
+import custom_scenes
+import scene_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def check(rt, oracle, scene, what):
+    lib = rt.amd_lib()
+    params = rt.render_params(seed=3)
+    want = oracle.render(scene, params)
+    try:
+        for ordered in (1, 0):
+            lib.rt_debug_set_traversal(ordered, -1)
+            for leaf in ((1, 2, 4, 8) if ordered else (-1,)):
+                lib.rt_debug_set_traversal(-1, leaf)
+                ds = rt.DeviceScene(scene)
+                assert ds.stats()["ordered"] == ordered
+                got = ds.render(params)
+                bad = np.flatnonzero(bits(got) != bits(want))
+                assert bad.size == 0, f"{what}: ordered={ordered} leaf={leaf}: {bad.size} of {want.size} values differ, first at {bad[:4]}"
+    finally:
+        lib.rt_debug_set_traversal(1, 4)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_exact_ties_resolve_as_the_reference_scan_does(rt, oracle, gpu, order):
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    check(rt, oracle, custom_scenes.tie_scene(cam, order), f"tie scene, order {order}")
+
+
+def test_single_primitive_and_empty_frame(rt, oracle, gpu):
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    check(rt, oracle, custom_scenes.single_sphere_scene(cam), "single sphere")
+    check(rt, oracle, custom_scenes.empty_frame_scene(cam), "empty frame")
+
+
+@pytest.mark.parametrize("name", [n for n in scene_cases.CASES if "smoke" not in n and "final" not in n])
+def test_both_traversals_match_the_oracle(rt, oracle, gpu, name):
+    """test_gpu_parity checks the default walk; here every scene that has two walks is rendered with each."""
+    hs = scene_cases.build(rt, name)
+    check(rt, oracle, hs, name)
