@@ -310,7 +310,8 @@ int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, doubl
 
 /* Test hook: runs the kernel's conservative f32 box test and the exact f64 slab test on n (ray, box) pairs —
  * rays[i] = (origin xyz, direction xyz), boxes[i] = (lo xyz, hi xyz), interval (tmin, tmax) — and reports, per pair,
- * whether each test enters the box.  The f32 test must enter wherever the exact one does (tests/test_gpu_parity.py). */
+ * whether each test enters the box: out_f32_hit bit 0 = the reference-order walk's test, bits 1 and 2 = the ordered walk's
+ * pair test with the box in slot 0 / slot 1.  The f32 tests must enter wherever the exact one does (tests/test_gpu_parity.py). */
 int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax,
                        uint8_t *out_exact_hit, uint8_t *out_f32_hit, int device);
 
@@ -350,8 +351,9 @@ int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
 
 /* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
  * (box, sphere, quad, other, shade): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
- * summed over waves. */
-int rt_debug_stage_profile(uint64_t out[15]);
+ * summed over waves; then four parts of the shade stage, cycles only (hit rebuild, unit-sphere rejection sampling, path end,
+ * job hand-out + camera ray — the shade slot itself keeps the remainder). */
+int rt_debug_stage_profile(uint64_t out[27]);
 
 /* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
  * live lanes wait for it; the box loop keeps running while th_box/64 of them are in it; use_lds = 0 forces the

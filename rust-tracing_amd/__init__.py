@@ -203,7 +203,8 @@ RT_DEBUG_LOG, RT_DEBUG_SIN, RT_DEBUG_ACOS, RT_DEBUG_ATAN2, RT_DEBUG_POW5, RT_DEB
 
 
 def debug_box_tests(rays, boxes, tmin, tmax, device=0):
-    """rt_debug_box_tests: (exact f64 test enters?, conservative f32 test enters?) per (ray, box) pair."""
+    """rt_debug_box_tests: per (ray, box) pair: does the exact f64 test enter? the conservative f32 test of the
+    reference-order walk? the packed pair test of the ordered walk (both slots must agree)?"""
     import numpy as np
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
@@ -214,7 +215,8 @@ def debug_box_tests(rays, boxes, tmin, tmax, device=0):
                                         boxes.ctypes.data_as(C.POINTER(C.c_double)), tmin, tmax,
                                         exact.ctypes.data_as(C.POINTER(C.c_uint8)), f32.ctypes.data_as(C.POINTER(C.c_uint8)),
                                         device), "rt_debug_box_tests")
-    return exact.astype(bool), f32.astype(bool)
+    assert (((f32 >> 1) & 1) == ((f32 >> 2) & 1)).all(), "the two slots of the pair test disagree on the same box"
+    return exact.astype(bool), (f32 & 1).astype(bool), ((f32 >> 1) & 1).astype(bool)
 
 
 def debug_compiled_nodes(host_scene, refit=True):
@@ -253,10 +255,11 @@ def debug_ordered_layout(host_scene) -> dict:
 
 def debug_stage_profile() -> dict:
     """rt_debug_stage_profile: per stage {rounds, lanes (mean active per round), cycles} of the last counted render."""
-    buf = (C.c_uint64 * 15)()
+    buf = (C.c_uint64 * 27)()
     _check(amd_lib().rt_debug_stage_profile(buf), "rt_debug_stage_profile")
     out = {}
-    for i, name in enumerate(("box", "sphere", "quad", "other", "shade")):
+    for i, name in enumerate(("box", "sphere", "quad", "other", "shade", "shade.rebuild", "shade.sample", "shade.path_end",
+                              "shade.new_job")):
         rounds, lanes, cycles = int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])
         out[name] = {"rounds": rounds, "mean_active_lanes": lanes / rounds if rounds else 0.0, "cycles": cycles}
     return out

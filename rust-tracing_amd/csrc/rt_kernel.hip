@@ -37,8 +37,8 @@ struct DMaterial { // 64 bytes
     uint32_t kind;
     uint32_t texture;
     uint32_t needs_uv; // the texture below reads (u, v): only ImageTexture does (src/texture.rs:83)
-    uint32_t _pad;
-    double albedo[3];
+    uint32_t solid;    // the texture is a SolidColor: its colour is copied into `albedo` (one dependent load fewer per hit)
+    double albedo[3];  // Metal's albedo, or the SolidColor's colour
     double fuzz;
     double ir;
     double _pad2;
@@ -61,7 +61,7 @@ struct KParams {
     double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
     double *att_stack;              // [max_depth][n_threads][3]: attenuations of the current path
     uint32_t *job_counter;
-    unsigned long long *counters;   // rt_counters as 10 u64, then per stage (5): rounds, active lanes, cycles; or null
+    unsigned long long *counters;   // rt_counters as 10 u64, then per profile slot (9): rounds, active lanes, cycles; or null
     rt_camera cam;
     uint64_t seed_mixed;            // mix64(seed + gamma)
     uint32_t n_nodes;
@@ -81,9 +81,10 @@ struct KParams {
     uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
     double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
     // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
-    const ONode *onodes;
+    const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
     uint32_t o_root;
     uint32_t lds_stack_off;
+    uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
 };
 
 struct Counts {
@@ -233,6 +234,7 @@ enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST
 #define RT_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for (tools/tune.py: 3 beats 2 and 4)
 #endif
 
+constexpr uint32_t PROF_SLOTS = 9;       // COUNT kernels: profile slots per wave (5 stages + 4 parts of the shade stage)
 constexpr uint32_t JOBS_PER_GRAB = 1024; // jobs a wave reserves at a time (16 sample-rows of one 8x8 tile)
 
 // What one box-stage round needs of a record
@@ -263,29 +265,31 @@ template <int LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned ch
     return n;
 }
 
-// Ordered layout: one record = four 16-byte quarters (child 0's box | its z and child 1's x | child 1's y, z | the two
-// child references); in the LDS each quarter is a table of its own, for the same bank-spreading reason as above.
-struct ONodeData {
-    float b0[6], b1[6];
+// Ordered layout, as the device holds it (global memory and LDS alike): seven tables indexed by record —
+//   X+ | X- | Y+ | Y- | Z+ | Z-   16 bytes each: (child 0, child 1) planes the ray ENTERS through on that axis, then the
+//                                  (child 0, child 1) planes it LEAVES through; "+" for rays with 1/d >= 0 on the axis
+//                                  (enter = lo, leave = hi), "-" the same four values swapped (enter = hi, leave = lo)
+//   R                              8 bytes: the two child references
+// A lane reads ONE of each axis pair, chosen by the sign of its ray's 1/d — the choice is a per-ray byte offset, so
+// the loaded registers already hold (near, near, far, far) pairs ready for the packed fmas: no per-visit selects.
+// Separate tables keep divergent 16-byte reads spread over all LDS banks (as for the threaded records above).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct OPair {
+    f32x2 nx, fx, ny, fy, nz, fz; // entering / leaving planes of (child 0, child 1) per axis
     uint32_t c0, c1;
 };
-template <int LDS> RT_DEV ONodeData load_onode(const KParams &P, const unsigned char *lds, uint32_t id) {
-    float4 q0, q1, q2, q3;
-    if constexpr (LDS != 0) {
-        const uint32_t quarter = P.lds_off_node_b; // bytes per table
-        q0 = reinterpret_cast<const float4 *>(lds)[id];
-        q1 = reinterpret_cast<const float4 *>(lds + quarter)[id];
-        q2 = reinterpret_cast<const float4 *>(lds + 2u * quarter)[id];
-        q3 = reinterpret_cast<const float4 *>(lds + 3u * quarter)[id];
-    } else {
-        const float4 *np = reinterpret_cast<const float4 *>(&P.onodes[id]);
-        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
-    }
-    ONodeData n;
-    n.b0[0] = q0.x; n.b0[1] = q0.y; n.b0[2] = q0.z; n.b0[3] = q0.w; n.b0[4] = q1.x; n.b0[5] = q1.y;
-    n.b1[0] = q1.z; n.b1[1] = q1.w; n.b1[2] = q2.x; n.b1[3] = q2.y; n.b1[4] = q2.z; n.b1[5] = q2.w;
-    n.c0 = __float_as_uint(q3.x);
-    n.c1 = __float_as_uint(q3.y);
+template <int LDS> RT_DEV OPair load_opair(const KParams &P, const unsigned char *lds, uint32_t id, uint32_t offx, uint32_t offy, uint32_t offz) {
+    const unsigned char *base = LDS != 0 ? lds : reinterpret_cast<const unsigned char *>(P.oimage);
+    const float4 qx = *reinterpret_cast<const float4 *>(base + offx + id * 16u);
+    const float4 qy = *reinterpret_cast<const float4 *>(base + offy + id * 16u);
+    const float4 qz = *reinterpret_cast<const float4 *>(base + offz + id * 16u);
+    const uint2 r = *reinterpret_cast<const uint2 *>(base + 6u * P.lds_off_node_b + id * 8u);
+    OPair n;
+    n.nx = f32x2{qx.x, qx.y}; n.fx = f32x2{qx.z, qx.w};
+    n.ny = f32x2{qy.x, qy.y}; n.fy = f32x2{qy.z, qy.w};
+    n.nz = f32x2{qz.x, qz.y}; n.fz = f32x2{qz.z, qz.w};
+    n.c0 = r.x;
+    n.c1 = r.y;
     return n;
 }
 
@@ -330,20 +334,60 @@ RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, f
     const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
     return !r.degenerate && gap > tol; // a NaN compares false: pass
 }
-// The same test on a box held as (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi); also returns where the ray enters it (for
-// choosing which child to walk first: any choice is correct, the nearer one prunes more)
-RT_DEV bool box_miss_f32_enter(const float b[6], const Ray32 &r, float tmin32, float tmax32, float &enter_out) {
-    const float t0x = (b[0] - r.ox) * r.ix, t1x = (b[1] - r.ox) * r.ix;
-    const float t0y = (b[2] - r.oy) * r.iy, t1y = (b[3] - r.oy) * r.iy;
-    const float t0z = (b[4] - r.oz) * r.iz, t1z = (b[5] - r.oz) * r.iz;
-    const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x) - r.ex, __builtin_fminf(t0y, t1y) - r.ey),
-                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z) - r.ez, tmin32));
-    const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x) + r.ex, __builtin_fmaxf(t0y, t1y) + r.ey),
-                                        __builtin_fminf(__builtin_fmaxf(t0z, t1z) + r.ez, tmax32));
-    const float gap = enter - leave;
-    const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
-    enter_out = enter;
-    return !r.degenerate && gap > tol; // a NaN compares false: pass
+// The ordered walk tests the two boxes of a record at once, in a form with half the instructions: per axis the plane
+// the ray meets first is known from the sign of 1/d (load_opair reads the table laid out for that sign), and each slab
+// distance is ONE fused multiply-add
+//     t = b * (1/d) - (o * (1/d) +- E)          (explicit fma: this f32 filter is not part of the f64 arithmetic contract)
+// with the product o * (1/d) and the outward shift E folded into two per-ray constants (`n` for entering planes, `f` for
+// leaving ones).  Error budget, relative to |o / d| on that axis: o -> f32 2^-24, the product 2^-24, adding E 2^-24 —
+// under E = 2^-21 |o / d|; relative to t itself: 1/d 2^-22 (conversion + v_rcp_f32), the fma's rounding 2^-24, tmin / tmax
+// 2^-24 — under the 2^-20 (|enter| + |leave|) the test tolerates.  So, as for box_miss_f32, it passes whenever the exact
+// test does.  Both boxes of the pair go through packed (2 x f32) fmas.
+struct RayPair32 {
+    float ix, iy, iz, nx, ny, nz, fx, fy, fz;
+    uint32_t offx, offy, offz; // byte offsets of the tables this ray reads (load_opair): X+ or X-, Y+ or Y-, Z+ or Z-
+    bool degenerate;
+};
+RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes) {
+    RayPair32 r;
+    r.ix = __builtin_amdgcn_rcpf((float)d.x); r.iy = __builtin_amdgcn_rcpf((float)d.y); r.iz = __builtin_amdgcn_rcpf((float)d.z);
+    const float px = (float)o.x * r.ix, py = (float)o.y * r.iy, pz = (float)o.z * r.iz;
+    const float ex = __builtin_fabsf(px) * 0x1p-21f, ey = __builtin_fabsf(py) * 0x1p-21f, ez = __builtin_fabsf(pz) * 0x1p-21f;
+    r.nx = px + ex; r.ny = py + ey; r.nz = pz + ez;
+    r.fx = px - ex; r.fy = py - ey; r.fz = pz - ez;
+    r.offx = (r.ix < 0.0f ? 1u : 0u) * table_bytes;
+    r.offy = (r.iy < 0.0f ? 3u : 2u) * table_bytes;
+    r.offz = (r.iz < 0.0f ? 5u : 4u) * table_bytes;
+    const float fsum = (ex + ey + ez) + (__builtin_fabsf(r.ix) + __builtin_fabsf(r.iy) + __builtin_fabsf(r.iz));
+    r.degenerate = !(fsum < __builtin_inff()); // an inf or a NaN anywhere: every box is entered
+    return r;
+}
+// enter0 / enter1: where the ray enters each box (for choosing which child to walk first: any choice is correct, the
+// nearer one prunes more)
+RT_DEV void box_pair_f32(const OPair &b, const RayPair32 &r, float tmin32, float tmax32, bool &miss0, bool &miss1, float &enter0,
+                         float &enter1) {
+    const f32x2 ix = {r.ix, r.ix}, iy = {r.iy, r.iy}, iz = {r.iz, r.iz};
+    const f32x2 tnx = __builtin_elementwise_fma(b.nx, ix, f32x2{-r.nx, -r.nx}), tfx = __builtin_elementwise_fma(b.fx, ix, f32x2{-r.fx, -r.fx});
+    const f32x2 tny = __builtin_elementwise_fma(b.ny, iy, f32x2{-r.ny, -r.ny}), tfy = __builtin_elementwise_fma(b.fy, iy, f32x2{-r.fy, -r.fy});
+    const f32x2 tnz = __builtin_elementwise_fma(b.nz, iz, f32x2{-r.nz, -r.nz}), tfz = __builtin_elementwise_fma(b.fz, iz, f32x2{-r.fz, -r.fz});
+    const float en0 = __builtin_fmaxf(__builtin_fmaxf(tnx.x, tny.x), __builtin_fmaxf(tnz.x, tmin32));
+    const float en1 = __builtin_fmaxf(__builtin_fmaxf(tnx.y, tny.y), __builtin_fmaxf(tnz.y, tmin32));
+    const float le0 = __builtin_fminf(__builtin_fminf(tfx.x, tfy.x), __builtin_fminf(tfz.x, tmax32));
+    const float le1 = __builtin_fminf(__builtin_fminf(tfx.y, tfy.y), __builtin_fminf(tfz.y, tmax32));
+    miss0 = !r.degenerate && (en0 - le0) > (__builtin_fabsf(en0) + __builtin_fabsf(le0)) * 0x1p-20f; // a NaN compares false: pass
+    miss1 = !r.degenerate && (en1 - le1) > (__builtin_fabsf(en1) + __builtin_fabsf(le1)) * 0x1p-20f;
+    enter0 = en0;
+    enter1 = en1;
+}
+// one box given as (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi) in both slots of a pair, as the "+" / "-" tables would hold it
+RT_DEV OPair opair_of_box(const float b[6], const RayPair32 &r) {
+    OPair p;
+    const bool sx = r.ix < 0.0f, sy = r.iy < 0.0f, sz = r.iz < 0.0f;
+    p.nx = f32x2{sx ? b[1] : b[0], sx ? b[1] : b[0]}; p.fx = f32x2{sx ? b[0] : b[1], sx ? b[0] : b[1]};
+    p.ny = f32x2{sy ? b[3] : b[2], sy ? b[3] : b[2]}; p.fy = f32x2{sy ? b[2] : b[3], sy ? b[2] : b[3]};
+    p.nz = f32x2{sz ? b[5] : b[4], sz ? b[5] : b[4]}; p.fz = f32x2{sz ? b[4] : b[5], sz ? b[4] : b[5]};
+    p.c0 = p.c1 = 0;
+    return p;
 }
 // The exact f64 test the kernel used before (and the oracle's tight mode): kept as the yardstick for the test hook
 RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, double tmin, double tmax) {
@@ -403,7 +447,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     double a = 1.0, time = 0.0;          // |d|^2 (Sphere::hit's `a`), ray time
     // f32 copies for the conservative box test: origin, 1/d, and the bound E on what rounding the origin to f32
     // can move a slab distance (see the box stage); `degenerate`: some 1/d or E is not finite -> enter every box
-    Ray32 r32 = make_ray32(o, d);
+    std::conditional_t<ORDERED, RayPair32, Ray32> r32;
+    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b); else r32 = make_ray32(o, d);
     float tmin32 = 0, tmax32 = 0;
     uint32_t job = 0;
     int32_t depth = 0;
@@ -474,21 +519,43 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     const uint32_t n_nodes = P.n_nodes;
     const int32_t w = P.cam.image_width, h = P.cam.image_height;
 
-    auto refresh_ray32 = [&]() { r32 = make_ray32(o, d); };
+    auto refresh_ray32 = [&]() {
+        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b);
+        else r32 = make_ray32(o, d);
+    };
     auto refresh_interval32 = [&]() {
         tmin32 = (float)cur_tmin;
         tmax32 = (float)cur_tmax;
     };
 
     // COUNT only: per stage, rounds run / lanes active in them / shader cycles spent (wave-level, kept by lane 0)
-    unsigned long long prof_rounds[5] = {0, 0, 0, 0, 0}, prof_lanes[5] = {0, 0, 0, 0, 0}, prof_cycles[5] = {0, 0, 0, 0, 0};
+    // slots 0-4: the stages; 5-8: parts of the shade stage (hit rebuild up to the material's first draw | unit-sphere
+    // rejection sampling | path end: attenuation chain and store | job hand-out and camera ray); the rest of a shade round
+    // (material evaluation, query start) stays in slot 4
+    // The accumulators live in the LDS (one row of PROF_SLOTS x 3 per wave, after the stacks): in registers they would be
+    // indexed dynamically and pushed to scratch, which distorts the very timings they record.
+    unsigned long long *const prof = reinterpret_cast<unsigned long long *>(lds_raw + P.lds_prof_off) + (threadIdx.x >> 6) * (PROF_SLOTS * 3u);
+    if (COUNT) {
+        if (lane < PROF_SLOTS * 3u) prof[lane] = 0;
+    }
+    auto prof_add = [&](uint32_t slot, uint32_t what, unsigned long long v) { // what: 0 rounds, 1 lanes, 2 cycles
+        if (lane == 0) prof[slot * 3u + what] += v;
+    };
+#define PROF_MARK(slot)                                                                                       \
+    do {                                                                                                      \
+        if (COUNT) {                                                                                          \
+            const unsigned long long t_mark = __builtin_amdgcn_s_memtime();                                   \
+            prof_add(slot, 2u, t_mark - t_prev);                                                              \
+            t_prev = t_mark;                                                                                  \
+        }                                                                                                     \
+    } while (0)
     unsigned long long t_prev = COUNT ? __builtin_amdgcn_s_memtime() : 0;
     uint32_t prev_run = ST_SHADE;
 
     for (;;) {
         if (COUNT) {
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();
-            prof_cycles[prev_run] += t_now - t_prev;
+            prof_add(prev_run, 2u, t_now - t_prev);
             t_prev = t_now;
         }
         // ---------------- scheduler: which stage has enough lanes queued? ----------------
@@ -514,8 +581,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
 
         if (COUNT) {
             prev_run = run;
-            prof_rounds[run] += 1;
-            prof_lanes[run] += run == ST_BOX ? c_box : run == ST_SPHERE ? c_sph : run == ST_QUAD ? c_quad : run == ST_OTHER ? c_oth : c_shade;
+            prof_add(run, 0u, 1);
+            prof_add(run, 1u, run == ST_BOX ? c_box : run == ST_SPHERE ? c_sph : run == ST_QUAD ? c_quad : run == ST_OTHER ? c_oth : c_shade);
         }
         if (run == ST_BOX) {
             // ---------------- box test + dispatch on the record kind ----------------
@@ -526,11 +593,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (stage == ST_BOX) {
                         // one record: both children's boxes; walk the nearer one, set the other aside
                         const uint32_t nid = node & NODE_INDEX;
-                        const ONodeData nd = load_onode<LDS>(P, lds_raw, nid);
+                        const OPair nd = load_opair<LDS>(P, lds_raw, nid, r32.offx, r32.offy, r32.offz);
                         if (COUNT) cn.node_visits++;
                         float e0, e1;
-                        bool h0 = !box_miss_f32_enter(nd.b0, r32, tmin32, tmax32, e0);
-                        bool h1 = !box_miss_f32_enter(nd.b1, r32, tmin32, tmax32, e1);
+                        bool m0, m1;
+                        box_pair_f32(nd, r32, tmin32, tmax32, m0, m1, e0, e1);
+                        bool h0 = !m0, h1 = !m1;
                         h0 = h0 && !(node & SKIP_CHILD0) && (nd.c0 >> OREF_KIND_SHIFT) != OK_EMPTY;
                         h1 = h1 && !(node & SKIP_CHILD1) && (nd.c1 >> OREF_KIND_SHIFT) != OK_EMPTY;
                         const bool one_first = h1 && (!h0 || e1 < e0);
@@ -566,7 +634,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                 }
                 in_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
-                if (COUNT && in_box * 64u >= P.th_box * live && in_box > 0) { prof_rounds[ST_BOX] += 1; prof_lanes[ST_BOX] += in_box; }
+                if (COUNT && in_box * 64u >= P.th_box * live && in_box > 0) { prof_add(ST_BOX, 0u, 1); prof_add(ST_BOX, 1u, in_box); }
             } while (in_box * 64u >= P.th_box * live && in_box > 0);
         } else if (HAS_SPHERES && run == ST_SPHERE) {
             // ---------------- Sphere::hit (src/sphere.rs:58-83), one sphere per round ----------------
@@ -841,10 +909,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // (src/vec3.rs:54-61) is the first draw of Lambertian, Metal and Isotropic alike.
                     V3 tex = v3(1.0, 1.0, 1.0);
                     V3 rs = v3(0.0, 0.0, 0.0);
+                    PROF_MARK(5);
                     if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
+                    PROF_MARK(6);
                     if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) {
-                        if constexpr (HAS_TEXTURES) tex = texture_value<COUNT>(P, m->texture, u, v, p, cn);
-                        else tex = from(P.texs[m->texture].color); // every texture is a SolidColor (src/texture.rs:32-36)
+                        if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, m->texture, u, v, p, cn);
+                        else tex = ld3(m->albedo); // every texture is a SolidColor (src/texture.rs:32-36): the colour was copied here
                     }
                     V3 attenuation = tex;
                     bool unit_attenuation = false;
@@ -894,13 +964,24 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         }
                     }
                 }
+                PROF_MARK(4);
                 if (path_done) {
                     // attenuation * ray_color(...), innermost first.  A zero terminal stays zero (attenuations are finite).
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
+                        // up to four parked attenuations per trip, their loads issued together (one memory latency, not
+                        // four); the products still run one after the other, last parked first
                         while (n_att > 0) {
-                            n_att--;
-                            const double *slot = att + (size_t)n_att * att_stride;
-                            result = v3(slot[0], slot[1], slot[2]) * result;
+                            V3 parked[4];
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const uint32_t level = n_att > j ? n_att - 1u - j : 0u;
+                                const double *slot = att + (size_t)level * att_stride;
+                                parked[j] = v3(slot[0], slot[1], slot[2]);
+                            }
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j)
+                                if (n_att > j) result = parked[j] * result;
+                            n_att = n_att > 4 ? n_att - 4 : 0;
                         }
                     }
                     double *dst = P.samples + (size_t)job * 3u;
@@ -909,6 +990,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     need_job = true;
                 }
             }
+            PROF_MARK(7);
             // ---- hand out jobs to the lanes that need one (wave-level: ballot + prefix count) ----
             const uint64_t want = __ballot(shading && need_job);
             const uint32_t n_want = (uint32_t)__popcll(want);
@@ -975,6 +1057,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 }
                 job_next += n_want < avail ? n_want : avail;
             }
+            PROF_MARK(8);
             // ---- start the closest-hit query of the next ray ----
             if (shading && stage == ST_SHADE && !need_job) {
                 if (COUNT) cn.rays++;
@@ -1002,11 +1085,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             if (lane == 0 && v) atomicAdd(&P.counters[q], v);
         }
         if (lane == 0) {
-            for (int q = 0; q < 5; ++q) {
-                atomicAdd(&P.counters[10 + q * 3 + 0], prof_rounds[q]);
-                atomicAdd(&P.counters[10 + q * 3 + 1], prof_lanes[q]);
-                atomicAdd(&P.counters[10 + q * 3 + 2], prof_cycles[q]);
-            }
+            for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) atomicAdd(&P.counters[10 + q], prof[q]);
         }
     }
 }
@@ -1081,7 +1160,14 @@ __global__ void debug_box_kernel(int64_t n, const double *__restrict__ rays, con
         hi32[k] = __double2float_ru(hi[k]);
     }
     exact_hit[idx] = box_miss_f64(lo, hi, o, d, tmin, tmax) ? 0 : 1;
-    f32_hit[idx] = box_miss_f32(lo32, hi32, make_ray32(o, d), (float)tmin, (float)tmax) ? 0 : 1;
+    const bool single = !box_miss_f32(lo32, hi32, make_ray32(o, d), (float)tmin, (float)tmax);
+    // the ordered walk's pair test, with the box in both slots
+    const float bb[6] = {lo32[0], hi32[0], lo32[1], hi32[1], lo32[2], hi32[2]};
+    bool m0, m1;
+    float e0, e1;
+    const RayPair32 rp = make_ray_pair32(o, d, 0u);
+    box_pair_f32(opair_of_box(bb, rp), rp, (float)tmin, (float)tmax, m0, m1, e0, e1);
+    f32_hit[idx] = (uint8_t)((single ? 1 : 0) | (m0 ? 0 : 2) | (m1 ? 0 : 4)); // bit 0: box_miss_f32, bits 1-2: box_pair_f32
 }
 
 // test hook: evaluates one device-side scalar function over arrays (rt_debug_eval)
@@ -1120,7 +1206,7 @@ namespace {
 
 thread_local std::string g_last_error;
 std::mutex g_stage_profile_mu;
-unsigned long long g_stage_profile[15] = {0}; // of the last counted render: 5 stages x (rounds, active lanes, cycles)
+unsigned long long g_stage_profile[27] = {0}; // of the last counted render: 9 slots x (rounds, active lanes, cycles)
 
 uint64_t rtk_host_mix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
@@ -1222,7 +1308,7 @@ struct rt_scene {
     DeviceArray<double> lut;
     uint32_t n_nodes = 0;
     bool ordered = false;                        // ordered layout (rt_ordered.hpp): onodes instead of nodes
-    DeviceArray<ONode> onodes;
+    DeviceArray<uint4> oimage;                   // ordered layout: the tables of load_opair (global copy)
     uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
     rt_scene_stats stats{};
     std::mutex mu;
@@ -1276,7 +1362,11 @@ size_t stack_bytes(const rt_scene *s, int lds) {
     if (!s->ordered) return 0;
     return (size_t)s->o_stack * (lds ? (size_t)LDS_THREADS * 2u : (size_t)GLOBAL_THREADS * 4u);
 }
-size_t dynamic_lds_bytes(const rt_scene *s, int lds) { return lds_image_bytes_for(s, lds) + stack_bytes(s, lds); }
+size_t prof_bytes(int lds) { return (size_t)((lds ? LDS_THREADS : GLOBAL_THREADS) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
+size_t prof_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 7u) & ~(size_t)7u; }
+size_t dynamic_lds_bytes(const rt_scene *s, int lds, bool counted) {
+    return prof_offset(s, lds) + (counted ? prof_bytes(lds) : 0);
+}
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
     dst.bytes = src.size() * sizeof(T);
@@ -1308,7 +1398,7 @@ void free_scene(rt_scene *s) {
     }
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
-    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->onodes.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr);
     delete s;
 }
 
@@ -1358,7 +1448,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
     const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
     const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
-    const size_t dyn_lds = dynamic_lds_bytes(scene, lds);
+    const size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
     // persistent grid: every resident wave pulls jobs until none are left
     int64_t grid = (int64_t)scene->n_cus * bpc;
     const int64_t waves_per_block = threads / 64;
@@ -1395,10 +1485,10 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             w.sample_bytes = need_samples;
         }
         if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
-        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 25 * sizeof(unsigned long long)));
+        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 40 * sizeof(unsigned long long)));
         ws = w;
     }
-    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 25 * sizeof(unsigned long long), stream));
+    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 40 * sizeof(unsigned long long), stream));
 
     KParams K{};
     K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
@@ -1421,7 +1511,8 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
-    K.onodes = scene->onodes.ptr; K.o_root = scene->o_root; K.lds_stack_off = lds_image_bytes_for(scene, lds);
+    K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.lds_stack_off = lds_image_bytes_for(scene, lds);
+    K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
         const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : tn.general));
@@ -1446,12 +1537,12 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
 
     if (counted) {
-        unsigned long long host[25];
+        unsigned long long host[40];
         HIP_TRY(hipMemcpyAsync(host, ws.counters, sizeof host, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         {
             std::lock_guard<std::mutex> lock(g_stage_profile_mu);
-            for (int q = 0; q < 15; ++q) g_stage_profile[q] = host[10 + q];
+            for (int q = 0; q < 27; ++q) g_stage_profile[q] = host[10 + q];
         }
         out_counters->samples = host[0]; out_counters->rays = host[1]; out_counters->node_visits = host[2];
         out_counters->sphere_tests = host[3]; out_counters->quad_tests = host[4]; out_counters->medium_visits = host[5];
@@ -1513,31 +1604,53 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     s->ordered = cs.ordered;
     s->o_root = cs.ordered_root;
     s->o_stack = cs.ordered_stack;
-    // LDS image (see load_node / load_onode): the 16-byte parts of the records as separate tables, then spheres and quads
+    // Node tables (load_node / load_opair): threaded records as two 16-byte halves, ordered records as six 16-byte plane
+    // tables and an 8-byte reference table.  LDS image = node tables | spheres | quads; every LDS level copies a prefix.
     {
         const size_t n = cs.ordered ? cs.onodes.size() : cs.nodes32.size();
-        const size_t parts = cs.ordered ? 4 : 2;
-        const size_t off_b = n * 16, off_sph = n * 16 * parts;
+        const size_t off_b = n * 16; // bytes of one 16-byte-per-record table
+        const size_t off_sph = cs.ordered ? ((n * (6 * 16 + 8) + 15u) & ~(size_t)15u) : n * 32;
+        std::vector<uint4> tables(off_sph / 16);
+        {
+            unsigned char *base = reinterpret_cast<unsigned char *>(tables.data());
+            if (cs.ordered) {
+                for (size_t i = 0; i < n; ++i) {
+                    const ONode &nd = cs.onodes[i];
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const float lo0 = nd.b0[2 * ax], hi0 = nd.b0[2 * ax + 1], lo1 = nd.b1[2 * ax], hi1 = nd.b1[2 * ax + 1];
+                        const float plus[4] = {lo0, lo1, hi0, hi1}, minus[4] = {hi0, hi1, lo0, lo1};
+                        memcpy(base + (size_t)(2 * ax) * off_b + i * 16, plus, 16);
+                        memcpy(base + (size_t)(2 * ax + 1) * off_b + i * 16, minus, 16);
+                    }
+                    memcpy(base + 6 * off_b + i * 8, nd.c, 8);
+                }
+            } else {
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(cs.nodes32.data());
+                for (size_t i = 0; i < n; ++i)
+                    for (size_t q = 0; q < 2; ++q) memcpy(base + q * off_b + i * 16, src + (i * 2 + q) * 16, 16);
+            }
+        }
+        if (cs.ordered) {
+            int urc = upload(s->oimage, tables);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+        }
+        s->lds_off_node_b = (uint32_t)off_b;
         const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
         const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
         const size_t stack = stack_bytes(s, 1);
         // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
-        s->lds_level = total + stack <= LDS_BUDGET_BYTES ? 3 : (off_sph + stack <= LDS_BUDGET_BYTES ? 1 : 0);
+        const size_t budget = LDS_BUDGET_BYTES - 4096; // (the instrumented kernels keep their profile rows behind the stacks)
+        s->lds_level = total + stack <= budget ? 3 : (off_sph + stack <= budget ? 1 : 0);
         if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries hold (record << 1 | slot) in 15 bits
         if (s->lds_level) {
-            // every level copies a prefix of the same image: node tables | spheres | quads
             const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
             std::vector<uint4> img(used / 16);
             unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
-            const unsigned char *src = cs.ordered ? reinterpret_cast<const unsigned char *>(cs.onodes.data())
-                                                  : reinterpret_cast<const unsigned char *>(cs.nodes32.data());
-            for (size_t i = 0; i < n; ++i)
-                for (size_t q = 0; q < parts; ++q) memcpy(base + q * off_b + i * 16, src + (i * parts + q) * 16, 16);
+            memcpy(base, tables.data(), off_sph);
             if (s->lds_level >= 2 && !cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
             if (s->lds_level == 3 && !cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
             int urc = upload(s->lds_image, img);
             if (urc != RT_OK) { free_scene(s); return urc; }
-            s->lds_off_node_b = (uint32_t)off_b;
             s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;
             s->lds_image_bytes = (uint32_t)used;
             s->lds_prefix_bytes[1] = (uint32_t)off_sph;
@@ -1551,7 +1664,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
             if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
             const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered);
             const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-            const size_t dyn = dynamic_lds_bytes(s, lds);
+            const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             int b = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
@@ -1566,14 +1679,19 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
         d.texture = m.texture >= 0 ? (uint32_t)m.texture : 0u;
         d.needs_uv = texture_needs_uv(cs.textures, m.texture) ? 1u : 0u;
         d.albedo[0] = m.albedo.x; d.albedo[1] = m.albedo.y; d.albedo[2] = m.albedo.z;
+        if (m.kind != RT_MATERIAL_METAL && m.kind != RT_MATERIAL_DIELECTRIC && m.texture >= 0 &&
+            cs.textures[(size_t)m.texture].kind == RT_TEXTURE_SOLID) {
+            const rt_vec3 &c = cs.textures[(size_t)m.texture].color;
+            d.solid = 1u;
+            d.albedo[0] = c.x; d.albedo[1] = c.y; d.albedo[2] = c.z;
+        }
         d.fuzz = m.fuzz;
         d.ir = m.ir;
         mats[i] = d;
     }
 
     int rc = RT_OK;
-    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->onodes, cs.onodes)) != RT_OK ||
-        (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
+    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
         (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
         (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
         (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
@@ -1584,13 +1702,13 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     }
     s->n_nodes = (uint32_t)cs.nodes.size();
     rt_scene_stats &st = s->stats;
-    st.node_bytes = cs.ordered ? s->onodes.bytes : s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
+    st.node_bytes = cs.ordered ? s->oimage.bytes : s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
     st.instance_bytes = s->insts.bytes; st.medium_bytes = s->media.bytes; st.material_bytes = s->mats.bytes;
     st.texture_bytes = s->texs.bytes; st.perlin_bytes = s->perlins.bytes; st.image_bytes = s->texels.bytes;
     st.n_nodes = (uint32_t)(cs.ordered ? cs.onodes.size() : cs.nodes.size()); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
     st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
     st.max_instance_depth = cs.max_instance_depth;
-    st.lds_nodes = s->lds_level ? st.n_nodes : 0; st.lds_bytes = s->lds_level ? (uint32_t)dynamic_lds_bytes(s, s->lds_level) : 0;
+    st.lds_nodes = s->lds_level ? st.n_nodes : 0; st.lds_bytes = s->lds_level ? (uint32_t)dynamic_lds_bytes(s, s->lds_level, false) : 0;
     st.ordered = cs.ordered ? 1u : 0u; st.stack_entries = cs.ordered ? cs.ordered_stack : 0u;
     *out_scene = s;
     return RT_OK;
@@ -1797,10 +1915,10 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
     return RT_OK;
 }
 
-int rt_debug_stage_profile(uint64_t out[15]) {
+int rt_debug_stage_profile(uint64_t out[27]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
     std::lock_guard<std::mutex> lock(g_stage_profile_mu);
-    for (int q = 0; q < 15; ++q) out[q] = g_stage_profile[q];
+    for (int q = 0; q < 27; ++q) out[q] = g_stage_profile[q];
     return RT_OK;
 }
 

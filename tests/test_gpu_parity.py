@@ -87,16 +87,18 @@ def test_f32_box_test_never_misses_what_the_exact_test_enters(rt, gpu):
     rays = np.concatenate([o, d], axis=1)
     boxes = np.concatenate([lo, hi], axis=1)
     for tmin, tmax in ((0.001, np.inf), (0.001, 1.0), (-np.inf, np.inf), (0.5, 0.5000001)):
-        exact, f32 = rt.debug_box_tests(rays, boxes, tmin, tmax)
-        bad = exact & ~f32
-        assert not bad.any(), (tmin, tmax, int(bad.sum()), rays[bad][:3], boxes[bad][:3])
+        exact, f32, pair = rt.debug_box_tests(rays, boxes, tmin, tmax)
+        for what, got in (("single", f32), ("pair", pair)):
+            bad = exact & ~got
+            assert not bad.any(), (what, tmin, tmax, int(bad.sum()), rays[bad][:3], boxes[bad][:3])
     # ... and it is not trivially "always enter": on rays that are not aimed at a face, edge or corner it rejects
     # practically everything the exact test rejects
     target = lo + rng.uniform(-1.0, 2.0, (n, 3)) * (hi - lo)
     rays = np.concatenate([o, target - o], axis=1)
-    exact, f32 = rt.debug_box_tests(rays, boxes, 0.001, np.inf)
-    assert not (exact & ~f32).any()
+    exact, f32, pair = rt.debug_box_tests(rays, boxes, 0.001, np.inf)
+    assert not (exact & ~f32).any() and not (exact & ~pair).any()
     assert 0.2 * n < (~exact).sum() and (~f32).sum() > 0.99 * (~exact).sum(), ((~f32).sum(), (~exact).sum())
+    assert (~pair).sum() > 0.99 * (~exact).sum(), ((~pair).sum(), (~exact).sum())
 
 
 # ---- whole-frame parity, every scene of the reference ---------------------------------------------------
