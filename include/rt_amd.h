@@ -350,17 +350,19 @@ typedef struct rt_debug_ordered {
 int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
 
 /* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
- * (box, sphere, quad, other, shade): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
- * summed over waves; then four parts of the shade stage, cycles only (hit rebuild, unit-sphere rejection sampling, path end,
- * job hand-out + camera ray — the shade slot itself keeps the remainder). */
-int rt_debug_stage_profile(uint64_t out[27]);
+ * (box, sphere, quad, other, shade, new-job): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
+ * summed over waves; then two parts of the shade stage, cycles only (hit rebuild, unit-sphere rejection sampling — the shade
+ * slot itself keeps the remainder). */
+int rt_debug_stage_profile(uint64_t out[24]);
 
 /* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
- * live lanes wait for it; the box loop keeps running while th_box/64 of them are in it; use_lds = 0 forces the
+ * live lanes wait for it (th_new: the path-end / next-job stage); the box loop keeps running while th_box/64 of them are in
+ * it; use_lds = 0 forces the
  * scene to be gathered from global memory even when it fits the LDS.  A negative threshold restores the built-in
  * per-scene-class preset; a negative use_lds keeps the current setting.
  * Affects speed only, never results.  Process-wide; not for concurrent use with renders. */
-int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds);
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds,
+                        int32_t th_new);
 
 const char *rt_last_error(void);
 const char *rt_version(void);

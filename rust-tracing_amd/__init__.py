@@ -193,7 +193,7 @@ RT_AMD_SYMBOLS = {
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
     "rt_debug_set_traversal": (C.c_int, [C.c_int32, C.c_int32]),
     "rt_debug_ordered_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "rt_debug_set_tuning": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_debug_set_tuning": (C.c_int, [C.c_int32] * 6),
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
 }
@@ -255,11 +255,10 @@ def debug_ordered_layout(host_scene) -> dict:
 
 def debug_stage_profile() -> dict:
     """rt_debug_stage_profile: per stage {rounds, lanes (mean active per round), cycles} of the last counted render."""
-    buf = (C.c_uint64 * 27)()
+    buf = (C.c_uint64 * 24)()
     _check(amd_lib().rt_debug_stage_profile(buf), "rt_debug_stage_profile")
     out = {}
-    for i, name in enumerate(("box", "sphere", "quad", "other", "shade", "shade.rebuild", "shade.sample", "shade.path_end",
-                              "shade.new_job")):
+    for i, name in enumerate(("box", "sphere", "quad", "other", "shade", "newjob", "shade.rebuild", "shade.sample")):
         rounds, lanes, cycles = int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])
         out[name] = {"rounds": rounds, "mean_active_lanes": lanes / rounds if rounds else 0.0, "cycles": cycles}
     return out

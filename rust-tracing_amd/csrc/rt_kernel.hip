@@ -59,7 +59,7 @@ struct KParams {
     const double *srgb_lut;
     double *out;
     double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
-    double *att_stack;              // [max_depth][n_threads][3]: attenuations of the current path
+    double *att_stack;              // [max_depth + 1][n_threads][3]: attenuations of the current path
     uint32_t *job_counter;
     unsigned long long *counters;   // rt_counters as 10 u64, then per profile slot (9): rounds, active lanes, cycles; or null
     rt_camera cam;
@@ -73,7 +73,7 @@ struct KParams {
     int32_t shard_index, shard_count, out_layout;
     int32_t tiles_x;
     uint32_t n_local_tiles;
-    uint32_t th_prim, th_other, th_shade; // scheduler thresholds, in 64ths of the live lanes
+    uint32_t th_prim, th_other, th_shade, th_new; // scheduler thresholds, in 64ths of the live lanes
     uint32_t th_box;                // the box loop keeps running while this many 64ths of the live lanes are in it
     // LDS-resident scene (SCENE_IN_LDS kernels): image to copy in, and where its parts start (bytes)
     const uint4 *lds_image;
@@ -228,13 +228,17 @@ template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, uint32_t tex, do
 // shade+next ray).  Each scheduler round the wave counts its lanes per stage with ballots and runs ONE stage for
 // all the lanes in it: the rare stages are deferred until enough lanes have queued up for them, so that every
 // instruction stream the wave issues has most of its 64 lanes active.
-enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST_SHADE = 4, ST_DONE = 5 };
+// (a lane waiting for the path-end stage holds ST_NEWJOB + Terminal: what its path ended on)
+enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST_SHADE = 4, ST_NEWJOB = 5, ST_DONE = 9 };
+// what a path ended on (ST_NEWJOB multiplies the parked attenuations back onto it): the background, Color::ONE (a light:
+// its emitted colour is the last thing parked), nothing (absorbed / depth exhausted); STORED: no path to finish
+enum Terminal : uint32_t { TERM_BACKGROUND = 0, TERM_ONE = 1, TERM_ZERO = 2, TERM_STORED = 3 };
 
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for (tools/tune.py: 3 beats 2 and 4)
 #endif
 
-constexpr uint32_t PROF_SLOTS = 9;       // COUNT kernels: profile slots per wave (5 stages + 4 parts of the shade stage)
+constexpr uint32_t PROF_SLOTS = 8;       // COUNT kernels: profile slots per wave (6 stages + 2 parts of the shade stage)
 constexpr uint32_t JOBS_PER_GRAB = 1024; // jobs a wave reserves at a time (16 sample-rows of one 8x8 tile)
 
 // What one box-stage round needs of a record
@@ -422,6 +426,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
                    HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
     constexpr bool HAS_OTHER = HAS_FRAMES || HAS_MEDIA;
+    // parked attenuations loaded per trip when a path ends: 4 where registers allow (the general kernels already spill)
+    constexpr uint32_t CHAIN = HAS_TEXTURES ? 1u : 4u;
     static_assert(!(ORDERED && HAS_MEDIA), "a ConstantMedium needs the reference's visiting order");
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
@@ -460,8 +466,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     int32_t best_inst = -1, cur_inst = -1;
     uint32_t node = 0, prim_cur = 0, prim_end = 0;
     uint32_t mode = 0; // ConstantMedium: 0 outside, 1 first boundary query, 2 second; bit 8: boundary was hit
-    uint32_t stage = ST_SHADE;
-    bool need_job = true;
+    uint32_t stage = ST_NEWJOB + TERM_STORED;
     // ---- ordered walk: a stack of children set aside (one entry per level at most), in the LDS, [level][thread] ----
     // entry < S_TOP: an inner record to visit; S_TOP | (record << 1 | slot): a leaf child whose box is tested again when
     // its turn comes (the interval has usually shrunk by then); S_EXIT: leave the current frame
@@ -529,9 +534,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     };
 
     // COUNT only: per stage, rounds run / lanes active in them / shader cycles spent (wave-level, kept by lane 0)
-    // slots 0-4: the stages; 5-8: parts of the shade stage (hit rebuild up to the material's first draw | unit-sphere
-    // rejection sampling | path end: attenuation chain and store | job hand-out and camera ray); the rest of a shade round
-    // (material evaluation, query start) stays in slot 4
+    // slots 0-5: the stages; 6-7: parts of the shade stage (hit rebuild up to the material's first draw | unit-sphere
+    // rejection sampling); the rest of a shade round (material evaluation, query start) stays in slot 4
     // The accumulators live in the LDS (one row of PROF_SLOTS x 3 per wave, after the stacks): in registers they would be
     // indexed dynamically and pushed to scratch, which distorts the very timings they record.
     unsigned long long *const prof = reinterpret_cast<unsigned long long *>(lds_raw + P.lds_prof_off) + (threadIdx.x >> 6) * (PROF_SLOTS * 3u);
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         }                                                                                                     \
     } while (0)
     unsigned long long t_prev = COUNT ? __builtin_amdgcn_s_memtime() : 0;
-    uint32_t prev_run = ST_SHADE;
+    uint32_t prev_run = ST_NEWJOB;
 
     for (;;) {
         if (COUNT) {
@@ -563,8 +567,16 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         const uint32_t c_sph = HAS_SPHERES ? (uint32_t)__popcll(__ballot(stage == ST_SPHERE)) : 0u;
         const uint32_t c_quad = HAS_QUADS ? (uint32_t)__popcll(__ballot(stage == ST_QUAD)) : 0u;
         const uint32_t c_oth = HAS_OTHER ? (uint32_t)__popcll(__ballot(stage == ST_OTHER)) : 0u;
-        const uint32_t c_shade = (uint32_t)__popcll(__ballot(stage == ST_SHADE));
-        const uint32_t live = c_box + c_sph + c_quad + c_oth + c_shade;
+        // a finished query that hit nothing needs no shading: the path ends on the background
+        if (stage == ST_SHADE && best_prim == PRIM_NONE) stage = ST_NEWJOB + TERM_BACKGROUND;
+        // th_new == 0: no separate path-end rounds — every shade round ends with the path-end block (for its own lanes that
+        // just finished and any that were waiting), and the two queues count as one (measured better on final_scene)
+        const bool merged = HAS_TEXTURES || P.th_new == 0; // (the general kernels are always merged: less code, fewer spills)
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(stage == ST_SHADE));
+        const uint32_t n_new = (uint32_t)__popcll(__ballot(stage - ST_NEWJOB < 4u));
+        const uint32_t c_shade = merged ? n_shade + n_new : n_shade;
+        const uint32_t c_new = merged ? 0u : n_new;
+        const uint32_t live = c_box + c_sph + c_quad + c_oth + n_shade + n_new;
         if (live == 0) break;
         uint32_t run = ST_BOX, best_c = 0;
         // a deferred stage becomes runnable once its queue holds th/64 of the live lanes ...
@@ -572,17 +584,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         if (c_quad * 64u >= P.th_prim * live && c_quad > best_c) { run = ST_QUAD; best_c = c_quad; }
         if (c_oth * 64u >= P.th_other * live && c_oth > best_c) { run = ST_OTHER; best_c = c_oth; }
         if (c_shade * 64u >= P.th_shade * live && c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
+        if (c_new * 64u >= P.th_new * live && c_new > best_c) { run = ST_NEWJOB; best_c = c_new; }
         if (best_c == 0 && c_box == 0) { // ... or when nothing else can run
             run = ST_SPHERE; best_c = c_sph;
             if (c_quad > best_c) { run = ST_QUAD; best_c = c_quad; }
             if (c_oth > best_c) { run = ST_OTHER; best_c = c_oth; }
             if (c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
+            if (c_new > best_c) { run = ST_NEWJOB; best_c = c_new; }
         }
 
         if (COUNT) {
             prev_run = run;
             prof_add(run, 0u, 1);
-            prof_add(run, 1u, run == ST_BOX ? c_box : run == ST_SPHERE ? c_sph : run == ST_QUAD ? c_quad : run == ST_OTHER ? c_oth : c_shade);
+            prof_add(run, 1u, run == ST_BOX ? c_box : run == ST_SPHERE ? c_sph : run == ST_QUAD ? c_quad : run == ST_OTHER ? c_oth : run == ST_SHADE ? c_shade : c_new);
         }
         if (run == ST_BOX) {
             // ---------------- box test + dispatch on the record kind ----------------
@@ -846,169 +860,179 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 }
                 stage = node >= n_nodes ? ST_SHADE : ST_BOX;
             }
-        } else {
-            // ---------------- shade the finished closest-hit query; start the next ray or the next path ----------------
-            const bool shading = stage == ST_SHADE;
-            V3 result = v3(0.0, 0.0, 0.0);
-            bool path_done = false;
-            if (shading && !need_job) {
-                // ray_color (src/renderer.rs:139-155), one level of the recursion per visit.  In this codebase a material
-                // that scatters emits nothing and the one that emits never scatters, so the recursion unrolls to
-                //     A_1 * (A_2 * ( ... (A_n * terminal)))
-                // evaluated innermost first; attenuations are parked in att_stack and multiplied back at the end.
-                if (best_prim == PRIM_NONE) {
-                    result = from(P.cam.background);
-                    path_done = true;
-                } else {
-                    // rebuild the HitRecord in its own frame, then carry it to the world
-                    V3 lo = o, ld = d; // all frames are closed at this point: (o, d) is the world ray
-                    if (HAS_FRAMES) ray_to_frame(P.insts, best_inst, lo, ld);
-                    V3 p = lo + ld * best_t; // Ray::at (src/ray.rs:30-32)
-                    V3 outward_normal;
-                    uint32_t mat;
-                    double u = 0.0, v = 0.0;
-                    const uint32_t pk = best_prim & PRIM_KIND_MASK, pi = best_prim & PRIM_INDEX_MASK;
-                    bool uv_from_sphere = false;
-                    if (HAS_SPHERES && (pk == PRIM_SPHERE || (!HAS_QUADS && !HAS_MEDIA))) { // src/sphere.rs:85-88
-                        const Sphere *s = &sphere_tab[pi];
-                        V3 center = ld3(s->center);
-                        if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
-                        outward_normal = div(p - center, s->radius);
-                        mat = s->material;
-                        uv_from_sphere = true;
-                    } else if (HAS_QUADS && (pk == PRIM_QUAD || !HAS_MEDIA)) { // src/quad.rs:118-132
-                        const Quad *qd = &quad_tab[pi];
-                        outward_normal = ld3(qd->normal);
-                        mat = qd->material;
-                        if (HAS_TEXTURES && P.mats[mat].needs_uv) {
-                            const V3 php = p - ld3(qd->q);
-                            const V3 qw = ld3(qd->w);
-                            u = dot(qw, cross(php, ld3(qd->v)));
-                            v = dot(qw, cross(ld3(qd->u), php));
-                        }
-                    } else { // ConstantMedium: normal := r.direction (src/constant_medium.rs:52-58)
-                        outward_normal = ld;
-                        mat = P.media[pi].phase_material;
+        }
+        bool start_query = false;
+        if (run == ST_SHADE) {
+            // ---------------- shade a closest hit: ray_color (src/renderer.rs:139-155), one level of the recursion per visit ----
+            // In this codebase a material that scatters emits nothing and the one that emits never scatters, so the recursion
+            // unrolls to  A_1 * (A_2 * ( ... (A_n * terminal)))  evaluated innermost first; attenuations are parked in att_stack
+            // and multiplied back when the path ends.  (A query that hit nothing went straight to ST_NEWJOB.)
+            if (stage == ST_SHADE) {
+                V3 result = v3(0.0, 0.0, 0.0);
+                bool path_done = false;
+                // rebuild the HitRecord in its own frame, then carry it to the world
+                V3 lo = o, ld = d; // all frames are closed at this point: (o, d) is the world ray
+                if (HAS_FRAMES) ray_to_frame(P.insts, best_inst, lo, ld);
+                V3 p = lo + ld * best_t; // Ray::at (src/ray.rs:30-32)
+                V3 outward_normal;
+                uint32_t mat;
+                double u = 0.0, v = 0.0;
+                const uint32_t pk = best_prim & PRIM_KIND_MASK, pi = best_prim & PRIM_INDEX_MASK;
+                bool uv_from_sphere = false;
+                if (HAS_SPHERES && (pk == PRIM_SPHERE || (!HAS_QUADS && !HAS_MEDIA))) { // src/sphere.rs:85-88
+                    const Sphere *s = &sphere_tab[pi];
+                    V3 center = ld3(s->center);
+                    if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
+                    outward_normal = div(p - center, s->radius);
+                    mat = s->material;
+                    uv_from_sphere = true;
+                } else if (HAS_QUADS && (pk == PRIM_QUAD || !HAS_MEDIA)) { // src/quad.rs:118-132
+                    const Quad *qd = &quad_tab[pi];
+                    outward_normal = ld3(qd->normal);
+                    mat = qd->material;
+                    if (HAS_TEXTURES && P.mats[mat].needs_uv) {
+                        const V3 php = p - ld3(qd->q);
+                        const V3 qw = ld3(qd->w);
+                        u = dot(qw, cross(php, ld3(qd->v)));
+                        v = dot(qw, cross(ld3(qd->u), php));
                     }
-                    const DMaterial *m = &P.mats[mat];
-                    if (HAS_TEXTURES && uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
-                        const double PI = 3.14159265358979323846264338327950288;
-                        const double theta = rt_acos(-outward_normal.y);
-                        const double phi = rt_atan2(-outward_normal.z, outward_normal.x) + PI;
-                        u = phi / (2.0 * PI);
-                        v = theta / PI;
-                    }
-                    // HitRecord::new (src/hittable.rs:22-37)
-                    const bool front_face = dot(ld, outward_normal) < 0.0;
-                    V3 normal = front_face ? outward_normal : -outward_normal;
-                    if (HAS_FRAMES) hit_to_world(P.insts, best_inst, p, normal);
+                } else { // ConstantMedium: normal := r.direction (src/constant_medium.rs:52-58)
+                    outward_normal = ld;
+                    mat = P.media[pi].phase_material;
+                }
+                const DMaterial *m = &P.mats[mat];
+                if (HAS_TEXTURES && uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
+                    const double PI = 3.14159265358979323846264338327950288;
+                    const double theta = rt_acos(-outward_normal.y);
+                    const double phi = rt_atan2(-outward_normal.z, outward_normal.x) + PI;
+                    u = phi / (2.0 * PI);
+                    v = theta / PI;
+                }
+                // HitRecord::new (src/hittable.rs:22-37)
+                const bool front_face = dot(ld, outward_normal) < 0.0;
+                V3 normal = front_face ? outward_normal : -outward_normal;
+                if (HAS_FRAMES) hit_to_world(P.insts, best_inst, p, normal);
 
-                    const uint32_t mk = m->kind;
-                    // Every material that reads a texture reads exactly one, after its random draws (textures draw
-                    // nothing): evaluate it at one place.  Likewise the unit-sphere rejection sample
-                    // (src/vec3.rs:54-61) is the first draw of Lambertian, Metal and Isotropic alike.
-                    V3 tex = v3(1.0, 1.0, 1.0);
-                    V3 rs = v3(0.0, 0.0, 0.0);
-                    PROF_MARK(5);
-                    if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
-                    PROF_MARK(6);
-                    if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) {
-                        if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, m->texture, u, v, p, cn);
-                        else tex = ld3(m->albedo); // every texture is a SolidColor (src/texture.rs:32-36): the colour was copied here
+                const uint32_t mk = m->kind;
+                // Every material that reads a texture reads exactly one, after its random draws (textures draw
+                // nothing): evaluate it at one place.  Likewise the unit-sphere rejection sample
+                // (src/vec3.rs:54-61) is the first draw of Lambertian, Metal and Isotropic alike.
+                V3 tex = v3(1.0, 1.0, 1.0);
+                V3 rs = v3(0.0, 0.0, 0.0);
+                PROF_MARK(6);
+                if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
+                PROF_MARK(7);
+                if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) {
+                    if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, m->texture, u, v, p, cn);
+                    else tex = ld3(m->albedo); // every texture is a SolidColor (src/texture.rs:32-36): the colour was copied here
+                }
+                V3 attenuation = tex;
+                bool unit_attenuation = false;
+                V3 new_dir = normal;
+                if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
+                    result = tex;
+                    path_done = true;
+                } else if (mk == RT_MATERIAL_LAMBERTIAN) { // src/material.rs:26-42
+                    const V3 scatter_direction = normal + normalize(rs);
+                    new_dir = near_zero(scatter_direction) ? normal : scatter_direction;
+                } else if (mk == RT_MATERIAL_METAL) { // src/material.rs:53-64
+                    const V3 refl = reflect(normalize(d), normal);
+                    const V3 reflected = refl + rs * m->fuzz;
+                    if (!(dot(reflected, normal) > 0.0)) path_done = true; // absorbed: emission (zero) only
+                    new_dir = reflected;
+                    attenuation = ld3(m->albedo);
+                } else if (mk == RT_MATERIAL_DIELECTRIC) { // src/material.rs:80-104
+                    const double refraction_ratio = front_face ? 1.0 / m->ir : m->ir;
+                    const V3 unit_direction = normalize(d);
+                    const double cos_theta = __builtin_fmin(dot(-unit_direction, normal), 1.0);
+                    const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
+                    bool do_reflect = refraction_ratio * sin_theta > 1.0;
+                    if (!do_reflect) { // `||` short-circuit: draw only when refraction is possible
+                        double r0 = (1.0 - refraction_ratio) / (1.0 + refraction_ratio);
+                        r0 = r0 * r0;
+                        const double reflectance = r0 + (1.0 - r0) * rt_pow5(1.0 - cos_theta);
+                        if (COUNT) cn.rng_draws++;
+                        do_reflect = reflectance > rng.random();
                     }
-                    V3 attenuation = tex;
-                    bool unit_attenuation = false;
-                    V3 new_dir = normal;
-                    if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
-                        result = tex;
+                    new_dir = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
+                    unit_attenuation = true; // Color::ONE: multiplying by it is the identity, nothing to park
+                } else { // RT_MATERIAL_ISOTROPIC, src/material.rs:132-138
+                    new_dir = normalize(rs);
+                }
+                if (!path_done) {
+                    if (!unit_attenuation) {
+                        double *slot = att + (size_t)n_att * att_stride;
+                        slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
+                        n_att++;
+                    }
+                    depth--;
+                    if (depth <= 0) { // the next ray_color call returns Color::ZERO at once
                         path_done = true;
-                    } else if (mk == RT_MATERIAL_LAMBERTIAN) { // src/material.rs:26-42
-                        const V3 scatter_direction = normal + normalize(rs);
-                        new_dir = near_zero(scatter_direction) ? normal : scatter_direction;
-                    } else if (mk == RT_MATERIAL_METAL) { // src/material.rs:53-64
-                        const V3 refl = reflect(normalize(d), normal);
-                        const V3 reflected = refl + rs * m->fuzz;
-                        if (!(dot(reflected, normal) > 0.0)) path_done = true; // absorbed: emission (zero) only
-                        new_dir = reflected;
-                        attenuation = ld3(m->albedo);
-                    } else if (mk == RT_MATERIAL_DIELECTRIC) { // src/material.rs:80-104
-                        const double refraction_ratio = front_face ? 1.0 / m->ir : m->ir;
-                        const V3 unit_direction = normalize(d);
-                        const double cos_theta = __builtin_fmin(dot(-unit_direction, normal), 1.0);
-                        const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
-                        bool do_reflect = refraction_ratio * sin_theta > 1.0;
-                        if (!do_reflect) { // `||` short-circuit: draw only when refraction is possible
-                            double r0 = (1.0 - refraction_ratio) / (1.0 + refraction_ratio);
-                            r0 = r0 * r0;
-                            const double reflectance = r0 + (1.0 - r0) * rt_pow5(1.0 - cos_theta);
-                            if (COUNT) cn.rng_draws++;
-                            do_reflect = reflectance > rng.random();
-                        }
-                        new_dir = do_reflect ? reflect(unit_direction, normal) : refract(unit_direction, normal, refraction_ratio);
-                        unit_attenuation = true; // Color::ONE: multiplying by it is the identity, nothing to park
-                    } else { // RT_MATERIAL_ISOTROPIC, src/material.rs:132-138
-                        new_dir = normalize(rs);
-                    }
-                    if (!path_done) {
-                        if (!unit_attenuation) {
-                            double *slot = att + (size_t)n_att * att_stride;
-                            slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
-                            n_att++;
-                        }
-                        depth--;
-                        if (depth <= 0) { // the next ray_color call returns Color::ZERO at once
-                            path_done = true;
-                        } else {
-                            o = p;
-                            d = new_dir;
-                        }
+                    } else {
+                        o = p;
+                        d = new_dir;
                     }
                 }
-                PROF_MARK(4);
                 if (path_done) {
-                    // attenuation * ray_color(...), innermost first.  A zero terminal stays zero (attenuations are finite).
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
-                        // up to four parked attenuations per trip, their loads issued together (one memory latency, not
-                        // four); the products still run one after the other, last parked first
+                        // a light: the emitted colour is parked like one more attenuation and the path ends on Color::ONE
+                        // (emitted * 1.0 is emitted, bit for bit), so the chain of products is written once, in ST_NEWJOB
+                        double *slot = att + (size_t)n_att * att_stride;
+                        slot[0] = result.x; slot[1] = result.y; slot[2] = result.z;
+                        n_att++;
+                        stage = ST_NEWJOB + TERM_ONE;
+                    } else {
+                        stage = ST_NEWJOB + TERM_ZERO; // absorbed, out of depth, or a black emitter
+                    }
+                } else {
+                    start_query = true; // of the scattered ray
+                }
+            }
+        }
+        if (run == ST_NEWJOB || (run == ST_SHADE && merged)) {
+            // ---------------- finish a path, take the next job, Camera::get_ray ----------------
+            const bool here = stage - ST_NEWJOB < 4u;
+            const uint32_t term = stage - ST_NEWJOB;
+            if (here && term != TERM_STORED) {
+                V3 result = v3(0.0, 0.0, 0.0);
+                if (term != TERM_ZERO) {
+                    result = term == TERM_BACKGROUND ? from(P.cam.background) : v3(1.0, 1.0, 1.0);
+                    // up to CHAIN parked attenuations per trip, their loads issued together (one memory latency, not CHAIN); the
+                    // products still run one after the other, last parked first.  A zero terminal stays zero (attenuations are finite).
+                    if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
                         while (n_att > 0) {
-                            V3 parked[4];
-#pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j) {
+                            V3 parked[CHAIN];
+                    #pragma unroll
+                            for (uint32_t j = 0; j < CHAIN; ++j) {
                                 const uint32_t level = n_att > j ? n_att - 1u - j : 0u;
                                 const double *slot = att + (size_t)level * att_stride;
                                 parked[j] = v3(slot[0], slot[1], slot[2]);
                             }
-#pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j)
+                    #pragma unroll
+                            for (uint32_t j = 0; j < CHAIN; ++j)
                                 if (n_att > j) result = parked[j] * result;
-                            n_att = n_att > 4 ? n_att - 4 : 0;
+                            n_att = n_att > CHAIN ? n_att - CHAIN : 0;
                         }
                     }
-                    double *dst = P.samples + (size_t)job * 3u;
-                    dst[0] = result.x; dst[1] = result.y; dst[2] = result.z;
-                    if (COUNT) cn.samples++;
-                    need_job = true;
                 }
+                double *dst = P.samples + (size_t)job * 3u;
+                dst[0] = result.x; dst[1] = result.y; dst[2] = result.z;
+                stage = ST_NEWJOB + TERM_STORED;
             }
-            PROF_MARK(7);
             // ---- hand out jobs to the lanes that need one (wave-level: ballot + prefix count) ----
-            const uint64_t want = __ballot(shading && need_job);
+            const uint64_t want = __ballot(here);
             const uint32_t n_want = (uint32_t)__popcll(want);
             if (n_want) {
-                if (jobs_left && job_end - job_next < n_want) {
-                    // not enough left in the wave's range: hand those out first (below), then reserve a new range
-                    // next round; simplest is to reserve now when the range is empty
-                    if (job_next == job_end) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(P.job_counter, JOBS_PER_GRAB);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= P.n_jobs) { jobs_left = false; }
-                        else { job_next = base; job_end = base + JOBS_PER_GRAB < P.n_jobs ? base + JOBS_PER_GRAB : P.n_jobs; }
-                    }
+                if (jobs_left && job_next == job_end) { // the wave's range is used up: reserve the next one
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.job_counter, JOBS_PER_GRAB);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base >= P.n_jobs) { jobs_left = false; }
+                    else { job_next = base; job_end = base + JOBS_PER_GRAB < P.n_jobs ? base + JOBS_PER_GRAB : P.n_jobs; }
                 }
                 const uint32_t avail = job_end - job_next;
                 const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-                if (shading && need_job) {
+                if (here) {
                     if (rank < avail) {
                         job = job_next + rank;
                         // job -> (local tile, sample, pixel): ((lt * S + s_rel) * 64 + p)
@@ -1048,29 +1072,28 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                             if (COUNT) cn.rng_draws += 1;
                             depth = P.max_depth;
                             n_att = 0;
-                            need_job = false;
+                            if (COUNT) cn.samples++;
+                            start_query = true; // of the camera ray
                         }
                         // a job of a padding pixel (edge tile) traces nothing; the lane asks again next round
-                    } else if (!jobs_left || avail == 0) {
-                        if (!jobs_left) stage = ST_DONE;
+                    } else if (!jobs_left) {
+                        stage = ST_DONE;
                     }
                 }
                 job_next += n_want < avail ? n_want : avail;
             }
-            PROF_MARK(8);
-            // ---- start the closest-hit query of the next ray ----
-            if (shading && stage == ST_SHADE && !need_job) {
-                if (COUNT) cn.rays++;
-                a = len2(d);
-                cur_tmin = 0.001; cur_tmax = INF; // (0.001, inf) (src/renderer.rs:144)
-                refresh_ray32();
-                refresh_interval32();
-                best_t = INF; best_prim = PRIM_NONE; best_inst = -1; cur_inst = -1;
-                mode = 0;
-                node = first_node;
-                sp = 0;
-                stage = ST_BOX;
-            }
+        }
+        if (start_query) { // the closest-hit query of a scattered or camera ray: world.hit(r, (0.001, inf)) (src/renderer.rs:144)
+            if (COUNT) cn.rays++;
+            a = len2(d);
+            cur_tmin = 0.001; cur_tmax = INF;
+            refresh_ray32();
+            refresh_interval32();
+            best_t = INF; best_prim = PRIM_NONE; best_inst = -1; cur_inst = -1;
+            mode = 0;
+            node = first_node;
+            sp = 0;
+            stage = ST_BOX;
         }
     }
 
@@ -1206,7 +1229,7 @@ namespace {
 
 thread_local std::string g_last_error;
 std::mutex g_stage_profile_mu;
-unsigned long long g_stage_profile[27] = {0}; // of the last counted render: 9 slots x (rounds, active lanes, cycles)
+unsigned long long g_stage_profile[PROF_SLOTS * 3] = {0}; // of the last counted render: per slot (rounds, active lanes, cycles)
 
 uint64_t rtk_host_mix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
@@ -1244,12 +1267,12 @@ struct Workspace {
 // The best values depend on the stage mix, so there is one preset per kernel instantiation, each picked with
 // tools/tune.py on MI355X (DESIGN.md "Scheduler"); a value >= 0 in `forced` (RT_TH_* variables, rt_debug_set_tuning)
 // overrides all presets.
-struct Thresholds { uint32_t prim, other, shade, box; };
+struct Thresholds { uint32_t prim, other, shade, box, newjob; };
 struct Tuning {
-    Thresholds general{8, 8, 48, 8};         // every feature (final_scene: 679 Msamples/s at 150 spp vs 619 with the spheres preset)
-    Thresholds spheres_solid{8, 16, 40, 24}; // random-spheres
-    Thresholds quads_frames{16, 16, 56, 4};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
-    int forced[4] = {-1, -1, -1, -1};        // prim, other, shade, box
+    Thresholds general{8, 8, 48, 8, 0};         // every feature (final_scene: 679 Msamples/s at 150 spp vs 619 with the spheres preset)
+    Thresholds spheres_solid{8, 16, 24, 16, 32}; // random-spheres
+    Thresholds quads_frames{8, 16, 40, 4, 8};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
+    int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     int refit = 1;   // 0: walk the reference's own (looser) boxes
     int ordered = 1; // 0: always walk the threaded records in the reference's order (scenes created afterwards)
@@ -1257,7 +1280,7 @@ struct Tuning {
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
         auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
-        env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]);
+        env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
         if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
         if (const char *e = getenv("RT_REFIT")) refit = atoi(e);
         if (const char *e = getenv("RT_ORDERED")) ordered = atoi(e);
@@ -1273,6 +1296,7 @@ struct Tuning {
         if (forced[1] >= 0) t.other = (uint32_t)forced[1];
         if (forced[2] >= 0) t.shade = (uint32_t)forced[2];
         if (forced[3] >= 0) t.box = (uint32_t)forced[3];
+        if (forced[4] >= 0) t.newjob = (uint32_t)forced[4];
         return t;
     }
 };
@@ -1461,7 +1485,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     {
         std::lock_guard<std::mutex> lock(scene->mu);
         Workspace &w = scene->workspaces[stream];
-        const size_t need_att = (size_t)p.max_depth * n_threads * 3u * sizeof(double);
+        const size_t need_att = ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double); // + a light's emitted colour
         const size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
         if (w.att_bytes < need_att || w.sample_bytes < need_samples) HIP_TRY(hipStreamSynchronize(stream));
         if (w.att_bytes < need_att) {
@@ -1516,7 +1540,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
         const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : tn.general));
-        K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box;
+        K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
     }
 
     const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
@@ -1542,7 +1566,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         HIP_TRY(hipStreamSynchronize(stream));
         {
             std::lock_guard<std::mutex> lock(g_stage_profile_mu);
-            for (int q = 0; q < 27; ++q) g_stage_profile[q] = host[10 + q];
+            for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) g_stage_profile[q] = host[10 + q];
         }
         out_counters->samples = host[0]; out_counters->rays = host[1]; out_counters->node_visits = host[2];
         out_counters->sphere_tests = host[3]; out_counters->quad_tests = host[4]; out_counters->medium_visits = host[5];
@@ -1802,9 +1826,9 @@ int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count,
     return RT_OK;
 }
 
-int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds) {
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds, int32_t th_new) {
     Tuning &t = tuning();
-    t.forced[0] = th_prim; t.forced[1] = th_other; t.forced[2] = th_shade; t.forced[3] = th_box;
+    t.forced[0] = th_prim; t.forced[1] = th_other; t.forced[2] = th_shade; t.forced[3] = th_box; t.forced[4] = th_new;
     if (use_lds >= 0) t.use_lds = use_lds;
     return RT_OK;
 }
@@ -1915,10 +1939,10 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
     return RT_OK;
 }
 
-int rt_debug_stage_profile(uint64_t out[27]) {
+int rt_debug_stage_profile(uint64_t out[24]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
     std::lock_guard<std::mutex> lock(g_stage_profile_mu);
-    for (int q = 0; q < 27; ++q) out[q] = g_stage_profile[q];
+    for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) out[q] = g_stage_profile[q];
     return RT_OK;
 }
 

@@ -55,12 +55,12 @@ def test_c2_random_spheres_1200x800_500spp_depth50(rt, gpu):
     # the same frame when the scene is gathered from global memory instead of the LDS (different kernel instantiation)
     lib = rt.amd_lib()
     try:
-        lib.rt_debug_set_tuning(-1, -1, -1, -1, 0)
+        lib.rt_debug_set_tuning(-1, -1, -1, -1, 0, -1)
         assert digest(render(rt, ds, hs)) == ref
-        lib.rt_debug_set_tuning(4, 8, 60, 40, 1)                               # and under any scheduler setting
+        lib.rt_debug_set_tuning(4, 8, 60, 40, 1, 20)                               # and under any scheduler setting
         assert digest(render(rt, ds, hs)) == ref
     finally:
-        lib.rt_debug_set_tuning(-1, -1, -1, -1, 1)
+        lib.rt_debug_set_tuning(-1, -1, -1, -1, 1, -1)
     # sanity of the content: a sky-lit scene, every pixel finite and lit, mean radiance per sample in a sane band
     f = whole.cpu().numpy().reshape(800, 1200, 3) / 500.0
     assert np.isfinite(f).all() and f.min() > 0.0 and 0.2 < f.mean() < 0.9

@@ -25,7 +25,7 @@ stream = torch.cuda.current_stream()
 axes = {}
 for part in args.grid.split(";"):
     k, v = part.split("="); axes[k] = [int(x) for x in v.split(",")]
-combos = list(itertools.product(axes["prim"], axes["other"], axes["shade"], axes["box"], axes.get("lds", [-1])))
+combos = list(itertools.product(axes["prim"], axes["other"], axes["shade"], axes["box"], axes.get("lds", [-1]), axes.get("new", [-1])))
 times = {c: [] for c in combos}
 lib = rt.amd_lib()
 params = rt.render_params(seed=1)
@@ -40,5 +40,5 @@ for r in range(args.rounds):
 msamples = hs.width * hs.height * args.spp / 1e6
 rows = sorted(((statistics.median(v), c) for c, v in times.items()))
 for t, c in rows[:12]:
-    print(f"prim={c[0]:3d} other={c[1]:3d} shade={c[2]:3d} box={c[3]:2d} lds={c[4]:2d}  {t:8.3f} ms  {msamples / t * 1e3:8.1f} Msamples/s")
+    print(f"prim={c[0]:3d} other={c[1]:3d} shade={c[2]:3d} box={c[3]:2d} lds={c[4]:2d} new={c[5]:3d}  {t:8.3f} ms  {msamples / t * 1e3:8.1f} Msamples/s")
 print("worst:", rows[-1])
