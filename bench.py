@@ -209,14 +209,17 @@ def main():
                 "executed_events_per_sample": {k: round(v, 3) for k, v in executed_per.items() if k != "samples"},
                 "walk": "own trees, nearest child first" if scene.stats()["ordered"] else "reference tree, reference order",
                 "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 5)},
+                        "frac": round(gbs / HBM_PEAK_GBS, 5),
+                        "note": "algorithmic bytes are scene records, served from the LDS / L2 copy of the scene, not from "
+                                "HBM: this is not the binding resource (DESIGN.md Roofline); `traffic` is the measured HBM bytes"},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, str(ROOT / "tests"))
             import oracle_lib  # the CPU restatement: timed here as the baseline, never part of the product path
             cores = oracle_lib.default_threads()
-            base_spp = 4 if args.workload in ("c2", "c3") else (10 if args.workload == "c1" else 1)
+            # a bounded sample, about 10 s of the host's cores: the first spp of the same frame (c1: the whole workload)
+            base_spp = {"c1": 10, "c2": 64, "c3": 256, "c4": 8}[args.workload]
             base_spp = min(base_spp, spp)
             t1 = time.perf_counter()
             oracle_lib.render(hs, rt.render_params(seed=RENDER_SEED, sample_end=base_spp), threads=cores)
