@@ -69,6 +69,7 @@ struct KParams {
     int32_t sample_begin;           // first sample of this launch
     uint32_t n_samples;             // samples per pixel in this launch
     uint32_t n_jobs;                // n_local_tiles * n_samples * 64
+    uint32_t jobs_per_grab;
     int32_t max_depth, accumulate;
     int32_t shard_index, shard_count, out_layout;
     int32_t tiles_x;
@@ -239,7 +240,10 @@ enum Terminal : uint32_t { TERM_BACKGROUND = 0, TERM_ONE = 1, TERM_ZERO = 2, TER
 #endif
 
 constexpr uint32_t PROF_SLOTS = 8;       // COUNT kernels: profile slots per wave (6 stages + 2 parts of the shade stage)
-constexpr uint32_t JOBS_PER_GRAB = 1024; // jobs a wave reserves at a time (16 sample-rows of one 8x8 tile)
+// Jobs a wave reserves at a time: a multiple of 64 (one sample-row of an 8x8 tile, so the lanes a wave starts together
+// trace neighbouring pixels).  Large grabs mean few atomics; small ones a short tail (the last grab of the slowest wave
+// is all that is left running at the end): launch_render picks the size so that every wave gets at least ~32 grabs.
+constexpr uint32_t MAX_JOBS_PER_GRAB = 1024, MIN_JOBS_PER_GRAB = 64;
 
 // What one box-stage round needs of a record
 struct NodeData {
@@ -1025,10 +1029,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             if (n_want) {
                 if (jobs_left && job_next == job_end) { // the wave's range is used up: reserve the next one
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.job_counter, JOBS_PER_GRAB);
+                    if (lane == 0) base = atomicAdd(P.job_counter, P.jobs_per_grab);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     if (base >= P.n_jobs) { jobs_left = false; }
-                    else { job_next = base; job_end = base + JOBS_PER_GRAB < P.n_jobs ? base + JOBS_PER_GRAB : P.n_jobs; }
+                    else { job_next = base; job_end = base + P.jobs_per_grab < P.n_jobs ? base + P.jobs_per_grab : P.n_jobs; }
                 }
                 const uint32_t avail = job_end - job_next;
                 const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
@@ -1276,6 +1280,7 @@ struct Tuning {
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     int refit = 1;   // 0: walk the reference's own (looser) boxes
     int ordered = 1; // 0: always walk the threaded records in the reference's order (scenes created afterwards)
+    int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     OrderedOptions ordered_options;
     size_t sample_buffer_bytes = (size_t)16 << 30;
     Tuning() {
@@ -1284,6 +1289,7 @@ struct Tuning {
         if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
         if (const char *e = getenv("RT_REFIT")) refit = atoi(e);
         if (const char *e = getenv("RT_ORDERED")) ordered = atoi(e);
+        if (const char *e = getenv("RT_JOBS_PER_GRAB")) jobs_per_grab = atoi(e);
         if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
         if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
         if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
@@ -1476,7 +1482,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     // persistent grid: every resident wave pulls jobs until none are left
     int64_t grid = (int64_t)scene->n_cus * bpc;
     const int64_t waves_per_block = threads / 64;
-    const int64_t max_useful = (n_local * 64 * chunk + JOBS_PER_GRAB * waves_per_block - 1) / (JOBS_PER_GRAB * waves_per_block);
+    const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_GRAB * waves_per_block - 1) / (MIN_JOBS_PER_GRAB * waves_per_block);
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
     const uint32_t n_threads = (uint32_t)(grid * threads);
@@ -1549,6 +1555,16 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         K.sample_begin = (int32_t)sb;
         K.n_samples = (uint32_t)ns;
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
+        {
+            // ~32 grabs per wave or more, rounded down to a multiple of 64 within [MIN, MAX]
+            const int64_t waves = grid * waves_per_block;
+            int64_t per_grab = (int64_t)K.n_jobs / (waves * 32);
+            if (tn.jobs_per_grab > 0) per_grab = tn.jobs_per_grab;
+            per_grab = per_grab / 64 * 64;
+            if (per_grab > MAX_JOBS_PER_GRAB) per_grab = MAX_JOBS_PER_GRAB;
+            if (per_grab < MIN_JOBS_PER_GRAB) per_grab = MIN_JOBS_PER_GRAB;
+            K.jobs_per_grab = (uint32_t)per_grab;
+        }
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
         {
