@@ -140,3 +140,21 @@ def empty_frame_scene(camera_from):
     nothing = s.translate(s.list([]), (1, 0, 0))
     return s.finish(s.list([nothing, s.sphere((0, 0, 0), 1.5, s.metal(0.7, 0.7, 0.7, 0.1)),
                             s.quad((-3, -2, -3), (6, 0, 0), (0, 0, 6), s.lambertian(0.3, 0.7, 0.3))]))
+
+
+def many_spheres_scene(camera_from, n, seed=5):
+    """n small spheres (Lambertian / Metal / Dielectric) scattered over a ground sphere, as one flat HittableList: sized
+    by the caller so that the compiled scene does or does not fit the LDS."""
+    import random
+    rnd = random.Random(seed)
+    s = CustomScene(camera_from, spp=4, depth=6, background=(0.7, 0.8, 1.0))
+    mats = [s.lambertian(rnd.random(), rnd.random(), rnd.random()) for _ in range(12)]
+    mats += [s.metal(0.5 + 0.5 * rnd.random(), 0.5 + 0.5 * rnd.random(), 0.5 + 0.5 * rnd.random(), 0.3 * rnd.random()) for _ in range(4)]
+    mats += [s.dielectric(1.5)]
+    items = [s.sphere((0.0, -1003.0, 0.0), 1000.0, mats[0])]
+    for _ in range(n):
+        x, z = rnd.uniform(-6, 6), rnd.uniform(-6, 6)
+        r = rnd.uniform(0.05, 0.25)
+        y = -3.0 + r + rnd.choice([0.0, 0.0, rnd.uniform(0, 3)])
+        items.append(s.sphere((x, y, z), r, rnd.choice(mats)))
+    return s.finish(s.list(items))

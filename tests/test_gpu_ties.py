@@ -48,3 +48,15 @@ def test_both_traversals_match_the_oracle(rt, oracle, gpu, name):
     """test_gpu_parity checks the default walk; here every scene that has two walks is rendered with each."""
     hs = scene_cases.build(rt, name)
     check(rt, oracle, hs, name)
+
+
+@pytest.mark.parametrize("n, lds_nodes_expected", [(900, True), (4000, False)])
+def test_scenes_larger_than_the_lds(rt, oracle, gpu, n, lds_nodes_expected):
+    """The BASELINE scenes all fit the LDS whole.  900 spheres: the records fit, the sphere table does not (it is read
+    from global memory); 4000: nothing fits, and the per-lane stacks switch to 4-byte entries."""
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.many_spheres_scene(cam, n)
+    st = rt.DeviceScene(scene).stats()
+    assert st["ordered"] == 1 and st["n_spheres"] == n + 1
+    assert (st["lds_nodes"] > 0) == lds_nodes_expected and st["lds_bytes"] < 160 * 1024
+    check(rt, oracle, scene, f"{n} spheres")
