@@ -330,7 +330,7 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
 
 /* Test / tuning hook: how scenes created from now on are walked.  ordered = 1 (default): scenes without a
  * ConstantMedium use the library's own trees, nearest child first; 0: every scene walks the reference's tree in the
- * reference's order.  leaf_max > 0: primitives per leaf of those trees at most.  Negative / zero: keep.
+ * reference's order.  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
  * Affects speed only, never results. */
 int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
 
@@ -339,13 +339,17 @@ int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
  * nodes: 16 words per record = two boxes as 6 floats (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi), two child references
  * (kind << 29 | (count - 1) << 26 | index; kind 0 record, 1 spheres, 2 quads, 3 instance, 7 empty), 2 unused.
  * spheres: 9 doubles = center, radius, center_vec, seq, is_moving.  quads: 10 = q, u, v, seq.
- * instances: 8 = offset, sin, cos, parent, flags (1 translate, 2 rotate), root record. */
+ * instances: 8 = offset, sin, cos, parent, flags (1 translate, 2 rotate), root record.
+ * steps: the world frame's sequence, 12 words per step = kind (0 tree, 1 medium bounded by one sphere, 2 medium with a
+ * boundary tree), a (tree: root record; medium: its index), b (boundary tree's root), unused, box as 6 floats, 2 unused.
+ * media: per medium, the index of its boundary sphere (kind 1 steps). `root` is the first step's tree. */
 typedef struct rt_debug_ordered {
-    int64_t cap_nodes, cap_spheres, cap_quads, cap_instances;
-    int64_t n_nodes, n_spheres, n_quads, n_instances;
+    int64_t cap_nodes, cap_spheres, cap_quads, cap_instances, cap_steps, cap_media;
+    int64_t n_nodes, n_spheres, n_quads, n_instances, n_steps, n_media;
     uint32_t ordered, root, stack_entries, _pad;
     uint32_t *nodes;
     double *spheres, *quads, *instances;
+    uint32_t *steps, *media;
 } rt_debug_ordered;
 int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
 

@@ -231,10 +231,11 @@ def debug_compiled_nodes(host_scene, refit=True):
 
 
 class DebugOrdered(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("cap_nodes", "cap_spheres", "cap_quads", "cap_instances",
-                                         "n_nodes", "n_spheres", "n_quads", "n_instances")] + \
+    _fields_ = [(n, C.c_int64) for n in ("cap_nodes", "cap_spheres", "cap_quads", "cap_instances", "cap_steps", "cap_media",
+                                         "n_nodes", "n_spheres", "n_quads", "n_instances", "n_steps", "n_media")] + \
                [(n, C.c_uint32) for n in ("ordered", "root", "stack_entries", "_pad")] + \
-               [("nodes", C.c_void_p), ("spheres", C.c_void_p), ("quads", C.c_void_p), ("instances", C.c_void_p)]
+               [("nodes", C.c_void_p), ("spheres", C.c_void_p), ("quads", C.c_void_p), ("instances", C.c_void_p),
+                ("steps", C.c_void_p), ("media", C.c_void_p)]
 
 
 def debug_ordered_layout(host_scene) -> dict:
@@ -245,12 +246,15 @@ def debug_ordered_layout(host_scene) -> dict:
     nodes = np.zeros((max(io.n_nodes, 1), 16), dtype=np.uint32)
     spheres = np.zeros((max(io.n_spheres, 1), 9)); quads = np.zeros((max(io.n_quads, 1), 10))
     insts = np.zeros((max(io.n_instances, 1), 8))
+    steps = np.zeros((max(io.n_steps, 1), 12), dtype=np.uint32); media = np.zeros(max(io.n_media, 1), dtype=np.uint32)
     io.cap_nodes, io.cap_spheres, io.cap_quads, io.cap_instances = len(nodes), len(spheres), len(quads), len(insts)
+    io.cap_steps, io.cap_media = len(steps), len(media)
     io.nodes, io.spheres, io.quads, io.instances = (a.ctypes.data for a in (nodes, spheres, quads, insts))
+    io.steps, io.media = steps.ctypes.data, media.ctypes.data
     _check(amd_lib().rt_debug_ordered_layout(C.addressof(host_scene.desc), C.addressof(io)), "rt_debug_ordered_layout")
     return {"ordered": bool(io.ordered), "root": int(io.root), "stack_entries": int(io.stack_entries),
             "nodes": nodes[:io.n_nodes], "spheres": spheres[:io.n_spheres], "quads": quads[:io.n_quads],
-            "instances": insts[:io.n_instances]}
+            "instances": insts[:io.n_instances], "steps": steps[:io.n_steps], "media": media[:io.n_media]}
 
 
 def debug_stage_profile() -> dict:

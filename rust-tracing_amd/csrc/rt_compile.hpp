@@ -90,7 +90,8 @@ struct CompiledScene {
     // ordered layout (rt_ordered.hpp), when the scene allows it: the primitive tables are then in leaf order
     bool ordered = false;
     std::vector<ONode> onodes;
-    uint32_t ordered_root = 0, ordered_stack = 0; // world root record; stack entries a lane needs at most
+    std::vector<OSeq> oseq;     // the world frame's sequence of trees and media
+    uint32_t ordered_stack = 0; // stack entries a lane needs at most
     std::vector<Sphere> spheres;
     std::vector<Quad> quads;
     std::vector<Instance> instances;

@@ -83,6 +83,8 @@ struct KParams {
     double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
     // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
     const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
+    const OSeq *oseq;               // the world frame's sequence of trees and media (rt_layout.h)
+    uint32_t n_oseq;
     uint32_t o_root;
     uint32_t lds_stack_off;
     uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
@@ -432,7 +434,6 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     constexpr bool HAS_OTHER = HAS_FRAMES || HAS_MEDIA;
     // parked attenuations loaded per trip when a path ends: 4 where registers allow (the general kernels already spill)
     constexpr uint32_t CHAIN = HAS_TEXTURES ? 1u : 4u;
-    static_assert(!(ORDERED && HAS_MEDIA), "a ConstantMedium needs the reference's visiting order");
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -476,14 +477,22 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // its turn comes (the interval has usually shrunk by then); S_EXIT: leave the current frame
     using StackT = std::conditional_t<LDS != 0, uint16_t, uint32_t>;
     constexpr uint32_t S_TOP = LDS != 0 ? 0x8000u : 0x80000000u, S_EXIT = LDS != 0 ? 0xffffu : 0xffffffffu;
-    constexpr uint32_t SKIP_CHILD0 = 0x40000000u, SKIP_CHILD1 = 0x80000000u, NODE_INDEX = 0x3fffffffu, NODE_FRAME_EXIT = 0xffffffffu;
+    constexpr uint32_t SKIP_CHILD0 = 0x40000000u, SKIP_CHILD1 = 0x80000000u, NODE_INDEX = 0x3fffffffu, NODE_FRAME_EXIT = 0xffffffffu,
+                       NODE_SEQ_NEXT = 0xfffffffeu; // ST_OTHER: leave the current frame / take the next step of the world's sequence
     StackT *const stack = reinterpret_cast<StackT *>(lds_raw + P.lds_stack_off) + threadIdx.x;
     uint32_t sp = 0;
+    uint32_t seq_pc = 0; // (scenes with media) the next step of the world frame's sequence
     const uint32_t first_node = ORDERED ? P.o_root : 0u;
     // what a lane does next in an ordered walk: go to `ref` if it has one, else take the last child set aside
     auto o_next = [&](bool have, uint32_t ref) {
         if (!have) {
-            if (sp == 0) { stage = ST_SHADE; return; }
+            if (sp == 0) { // this tree is done
+                if constexpr (HAS_MEDIA) { // ... the world's sequence may go on; a boundary query reports to its medium
+                    if (seq_pc < P.n_oseq || (mode & 3u) != 0) { node = NODE_SEQ_NEXT; stage = ST_OTHER; return; }
+                }
+                stage = ST_SHADE;
+                return;
+            }
             sp--;
             const uint32_t e = stack[sp * THREADS];
             if (e == S_EXIT) { node = NODE_FRAME_EXIT; stage = ST_OTHER; return; }
@@ -512,6 +521,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // everything before it, a sphere nothing), so applying it pairwise in ANY visiting order ends with the primitive the
     // reference's scan ends with.  `seq` is the scan position.
     auto wins_tie = [&](uint32_t my_seq, bool i_am_quad) -> bool {
+        // (a medium hit is always earlier in the scan than whatever is tested now: the sequence runs in scan order)
+        if (HAS_MEDIA && (best_prim & PRIM_KIND_MASK) == PRIM_MEDIUM) return i_am_quad;
         const bool best_is_quad = (best_prim & PRIM_KIND_MASK) == PRIM_QUAD;
         const uint32_t bi = best_prim & PRIM_INDEX_MASK;
         const uint32_t best_seq = best_is_quad ? quad_tab[bi].seq : (sphere_tab[bi].seq_moving >> 1);
@@ -537,6 +548,116 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         tmax32 = (float)cur_tmax;
     };
 
+    // ---- ConstantMedium::hit (src/constant_medium.rs:33-71), shared by both walks ----
+    // a medium bounded by one Sphere: the two boundary.hit calls solve the same quadratic (src/sphere.rs:58-83), first over
+    // (-inf, inf), then over (t1 + 0.0001, inf)
+    auto medium_sphere_hit = [&](uint32_t na) {
+        // ConstantMedium::hit with a Sphere boundary (src/constant_medium.rs:33-71): the two boundary.hit calls
+        // solve the same quadratic (src/sphere.rs:58-83), first over (-inf, inf), then over (t1 + 0.0001, inf)
+        if (COUNT) { cn.medium_visits++; cn.sphere_tests++; }
+        const Medium md = P.media[na];
+        const Sphere *s = &sphere_tab[md.first_node];
+        V3 center = ld3(s->center);
+        if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
+        const V3 oc = o - center;
+        const double half_b = dot(oc, d);
+        const double c = len2(oc) - s->radius * s->radius;
+        const double discriminant = half_b * half_b - a * c;
+        if (!(discriminant < 0.0)) {
+            const double sqrtd = __builtin_sqrt(discriminant);
+            const double root_a = (-half_b - sqrtd) / a, root_b = (-half_b + sqrtd) / a;
+            // Interval::surrounds is strict at both ends (src/interval.rs:44-46)
+            const bool a1 = -INF < root_a && root_a < INF, b1 = -INF < root_b && root_b < INF;
+            if (a1 || b1) {
+                const double t1 = a1 ? root_a : root_b;
+                if (COUNT) cn.sphere_tests++;
+                const double lo2 = t1 + 0.0001;
+                const bool a2 = lo2 < root_a && root_a < INF, b2 = lo2 < root_b && root_b < INF;
+                if (a2 || b2) {
+                    const double t2 = a2 ? root_a : root_b;
+                    double h1 = __builtin_fmax(t1, 0.001);
+                    const double h2 = __builtin_fmin(t2, best_t);
+                    if (h1 < h2) {
+                        h1 = __builtin_fmax(h1, 0.0);
+                        const double ray_length = __builtin_sqrt(len2(d));
+                        const double distance_inside_boundary = (h2 - h1) * ray_length;
+                        if (COUNT) cn.rng_draws++;
+                        const double hit_distance = md.neg_inv_density * rt_log(rng.random());
+                        if (hit_distance <= distance_inside_boundary) {
+                            best_t = h1 + hit_distance / ray_length;
+                            best_prim = PRIM_MEDIUM | na;
+                            best_inst = cur_inst;
+                            cur_tmax = best_t;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    // a boundary query (mode 1 or 2) of medium `na` has just ended; true: the second query has to run (interval set)
+    auto medium_boundary_done = [&](uint32_t na) -> bool {
+        bool again = false;
+        const bool sub_hit = (mode & 0x100u) != 0;
+        if ((mode & 3u) == 1) {
+            if (sub_hit) { // boundary.hit(r, (hit1.t + 0.0001, inf)) (src/constant_medium.rs:36-38)
+                med_t1 = cur_tmax;
+                mode = 2;
+                cur_tmin = med_t1 + 0.0001;
+                cur_tmax = INF;
+                again = true;
+            }
+        } else if (sub_hit) { // src/constant_medium.rs:40-61
+            double h1 = __builtin_fmax(med_t1, 0.001);
+            const double h2 = __builtin_fmin(cur_tmax, best_t);
+            if (h1 < h2) {
+                h1 = __builtin_fmax(h1, 0.0);
+                const double ray_length = __builtin_sqrt(len2(d));
+                const double distance_inside_boundary = (h2 - h1) * ray_length;
+                if (COUNT) cn.rng_draws++;
+                const double hit_distance = P.media[na].neg_inv_density * rt_log(rng.random());
+                if (hit_distance <= distance_inside_boundary) {
+                    best_t = h1 + hit_distance / ray_length;
+                    best_prim = PRIM_MEDIUM | na;
+                    best_inst = cur_inst;
+                }
+            }
+        }
+        if (!again) {
+            mode = 0;
+            cur_tmin = 0.001;
+            cur_tmax = best_t;
+        }
+        return again;
+    };
+    // (scenes with media) take the next steps of the world frame's sequence (rt_layout.h OSeq) until one needs a walk:
+    auto seq_advance = [&]() {
+        if constexpr (ORDERED && HAS_MEDIA) {
+            // skip the steps whose box the ray cannot reach within (0.001, closest so far): a tree there holds
+            // nothing closer, a medium there draws nothing (src/constant_medium.rs:40-44: t1 >= t2)
+            stage = ST_SHADE;
+            while (seq_pc < P.n_oseq) {
+                const OSeq *rec = &P.oseq[seq_pc];
+                seq_pc++;
+                float enter;
+                bool miss0, miss1;
+                box_pair_f32(opair_of_box(rec->box, r32), r32, (float)cur_tmin, (float)cur_tmax, miss0, miss1, enter, enter);
+                if (miss0) continue;
+                if (rec->kind == OSEQ_TREE) {
+                    node = rec->a; sp = 0; stage = ST_BOX;
+                } else if (rec->kind == OSEQ_MEDIUM_SPHERE) {
+                    medium_sphere_hit(rec->a); // (may lower cur_tmax: the following steps are tested against it)
+                    continue;
+                } else { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
+                    if (COUNT) cn.medium_visits++;
+                    mode = 1;
+                    cur_tmin = -INF;
+                    cur_tmax = INF;
+                    node = rec->b; sp = 0; stage = ST_BOX;
+                }
+                break;
+            }
+        }
+    };
     // COUNT only: per stage, rounds run / lanes active in them / shader cycles spent (wave-level, kept by lane 0)
     // slots 0-5: the stages; 6-7: parts of the shade stage (hit rebuild up to the material's first draw | unit-sphere
     // rejection sampling); the rest of a shade round (material evaluation, query start) stays in slot 4
@@ -672,7 +793,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     auto inside = [&](double root) {
                         if (cur_tmin < root && root < cur_tmax) return true;
                         if constexpr (ORDERED)
-                            return cur_tmin < root && root == cur_tmax && best_prim != PRIM_NONE && wins_tie(s->seq_moving >> 1, false);
+                            return cur_tmin < root && root == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) &&
+                                   wins_tie(s->seq_moving >> 1, false); // (a boundary query only wants t: ties are moot)
                         return false;
                     };
                     double root = (-half_b - sqrtd) / a;
@@ -706,7 +828,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const double t = (qd->d - dot(normal, o)) / denom;
                     if (!(cur_tmin <= t && t <= cur_tmax)) continue; // Interval::contains (src/interval.rs:40-42)
                     if constexpr (ORDERED) // the ordered walk settles ties explicitly (see wins_tie)
-                        if (t == cur_tmax && best_prim != PRIM_NONE && !wins_tie(qd->seq, true)) continue;
+                        if (t == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) && !wins_tie(qd->seq, true)) continue;
                     const V3 intersection = o + d * t;
                     const V3 php = intersection - ld3(qd->q);
                     const V3 qw = ld3(qd->w);
@@ -725,6 +847,17 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         } else if (HAS_OTHER && run == ST_OTHER) {
             // ---------------- frame changes and ConstantMedium steps ----------------
             if constexpr (ORDERED) {
+                if (HAS_MEDIA && stage == ST_OTHER && node == NODE_SEQ_NEXT) {
+                    // ---- the world frame's sequence (rt_layout.h OSeq): a tree or a boundary query has ended ----
+                    bool again = false;
+                    if ((mode & 3u) != 0) { // a boundary query of the medium at the previous step
+                        const OSeq *rec = &P.oseq[seq_pc - 1u];
+                        again = medium_boundary_done(rec->a);
+                        if (again) { node = rec->b; sp = 0; stage = ST_BOX; }
+                    }
+                    if (!again) seq_advance();
+                    refresh_interval32();
+                } else
                 if (stage == ST_OTHER) { // enter the frame of instance `node`, or leave the current one
                     const bool leaving = node == NODE_FRAME_EXIT;
                     const size_t ws = P.n_threads;
@@ -778,83 +911,11 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     cur_tmax = INF;
                     node = node + 1;
                 } else if (HAS_MEDIA && kind == NK_MEDIUM_SPHERE) {
-                    // ConstantMedium::hit with a Sphere boundary (src/constant_medium.rs:33-71): the two boundary.hit calls
-                    // solve the same quadratic (src/sphere.rs:58-83), first over (-inf, inf), then over (t1 + 0.0001, inf)
-                    if (COUNT) { cn.medium_visits++; cn.sphere_tests++; }
-                    const Medium md = P.media[na];
-                    const Sphere *s = &sphere_tab[md.first_node];
-                    V3 center = ld3(s->center);
-                    if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
-                    const V3 oc = o - center;
-                    const double half_b = dot(oc, d);
-                    const double c = len2(oc) - s->radius * s->radius;
-                    const double discriminant = half_b * half_b - a * c;
-                    if (!(discriminant < 0.0)) {
-                        const double sqrtd = __builtin_sqrt(discriminant);
-                        const double root_a = (-half_b - sqrtd) / a, root_b = (-half_b + sqrtd) / a;
-                        // Interval::surrounds is strict at both ends (src/interval.rs:44-46)
-                        const bool a1 = -INF < root_a && root_a < INF, b1 = -INF < root_b && root_b < INF;
-                        if (a1 || b1) {
-                            const double t1 = a1 ? root_a : root_b;
-                            if (COUNT) cn.sphere_tests++;
-                            const double lo2 = t1 + 0.0001;
-                            const bool a2 = lo2 < root_a && root_a < INF, b2 = lo2 < root_b && root_b < INF;
-                            if (a2 || b2) {
-                                const double t2 = a2 ? root_a : root_b;
-                                double h1 = __builtin_fmax(t1, 0.001);
-                                const double h2 = __builtin_fmin(t2, best_t);
-                                if (h1 < h2) {
-                                    h1 = __builtin_fmax(h1, 0.0);
-                                    const double ray_length = __builtin_sqrt(len2(d));
-                                    const double distance_inside_boundary = (h2 - h1) * ray_length;
-                                    if (COUNT) cn.rng_draws++;
-                                    const double hit_distance = md.neg_inv_density * rt_log(rng.random());
-                                    if (hit_distance <= distance_inside_boundary) {
-                                        best_t = h1 + hit_distance / ray_length;
-                                        best_prim = PRIM_MEDIUM | na;
-                                        best_inst = cur_inst;
-                                        cur_tmax = best_t;
-                                    }
-                                }
-                            }
-                        }
-                    }
+                    medium_sphere_hit(na);
                     node = nd.skip;
                 } else if (HAS_MEDIA) { // NK_MEDIUM_EXIT
-                    bool again = false;
-                    const bool sub_hit = (mode & 0x100u) != 0;
-                    if ((mode & 3u) == 1) {
-                        if (sub_hit) { // boundary.hit(r, (hit1.t + 0.0001, inf)) (src/constant_medium.rs:36-38)
-                            med_t1 = cur_tmax;
-                            mode = 2;
-                            cur_tmin = med_t1 + 0.0001;
-                            cur_tmax = INF;
-                            again = true;
-                        }
-                    } else if (sub_hit) { // src/constant_medium.rs:40-61
-                        double h1 = __builtin_fmax(med_t1, 0.001);
-                        const double h2 = __builtin_fmin(cur_tmax, best_t);
-                        if (h1 < h2) {
-                            h1 = __builtin_fmax(h1, 0.0);
-                            const double ray_length = __builtin_sqrt(len2(d));
-                            const double distance_inside_boundary = (h2 - h1) * ray_length;
-                            if (COUNT) cn.rng_draws++;
-                            const double hit_distance = P.media[na].neg_inv_density * rt_log(rng.random());
-                            if (hit_distance <= distance_inside_boundary) {
-                                best_t = h1 + hit_distance / ray_length;
-                                best_prim = PRIM_MEDIUM | na;
-                                best_inst = cur_inst;
-                            }
-                        }
-                    }
-                    if (again) {
-                        node = P.media[na].first_node;
-                    } else {
-                        mode = 0;
-                        cur_tmin = 0.001;
-                        cur_tmax = best_t;
-                        node = node + 1;
-                    }
+                    if (medium_boundary_done(na)) node = P.media[na].first_node;
+                    else node = node + 1;
                 }
                 if (kind == NK_INST_ENTER || kind == NK_INST_EXIT) {
                     refresh_ray32();
@@ -1098,6 +1159,14 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             node = first_node;
             sp = 0;
             stage = ST_BOX;
+            if constexpr (ORDERED && HAS_MEDIA) { // the world's sequence starts over
+                seq_pc = 1; // (its first step is a tree: first_node)
+                if (first_node == NODE_SEQ_NEXT) { // ... or a medium: taken here, while the lanes starting a query are together
+                    seq_pc = 0;
+                    seq_advance();
+                    refresh_interval32();
+                }
+            }
         }
     }
 
@@ -1273,7 +1342,8 @@ struct Workspace {
 // overrides all presets.
 struct Thresholds { uint32_t prim, other, shade, box, newjob; };
 struct Tuning {
-    Thresholds general{8, 8, 48, 8, 0};         // every feature (final_scene: 679 Msamples/s at 150 spp vs 619 with the spheres preset)
+    Thresholds general{8, 8, 48, 8, 0};
+    Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
     Thresholds spheres_solid{8, 16, 24, 16, 32}; // random-spheres
     Thresholds quads_frames{8, 16, 40, 4, 8};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
     int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
@@ -1339,6 +1409,8 @@ struct rt_scene {
     uint32_t n_nodes = 0;
     bool ordered = false;                        // ordered layout (rt_ordered.hpp): onodes instead of nodes
     DeviceArray<uint4> oimage;                   // ordered layout: the tables of load_opair (global copy)
+    DeviceArray<OSeq> oseq;                      // ... and the world frame's sequence
+    uint32_t n_oseq = 0;
     uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
     rt_scene_stats stats{};
     std::mutex mu;
@@ -1359,11 +1431,11 @@ constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 // ones for scenes that fit the LDS entirely and use a subset of the features (BASELINE configs 1/2 and 3).
 constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
 constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
-constexpr uint32_t FEAT_NO_MEDIA = F_ALL & ~F_MEDIA;       // the ordered walk's general kernel
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
     if (lds == 3 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
     if (lds == 3 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
-    return ordered ? FEAT_NO_MEDIA : F_ALL;
+    (void)ordered;
+    return F_ALL;
 }
 const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered) {
 #define RT_PICK(L, T, F, O) (counted ? (const void *)path_kernel<true, L, T, F, O> : (const void *)path_kernel<false, L, T, F, O>)
@@ -1371,10 +1443,10 @@ const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered) {
         if (lds == 3) {
             if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true);
             if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true);
-            return RT_PICK(3, LDS_THREADS, FEAT_NO_MEDIA, true);
+            return RT_PICK(3, LDS_THREADS, F_ALL, true);
         }
-        if (lds == 1) return RT_PICK(1, LDS_THREADS, FEAT_NO_MEDIA, true);
-        return RT_PICK(0, GLOBAL_THREADS, FEAT_NO_MEDIA, true);
+        if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL, true);
+        return RT_PICK(0, GLOBAL_THREADS, F_ALL, true);
     }
     if (lds == 3) {
         if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false);
@@ -1428,7 +1500,7 @@ void free_scene(rt_scene *s) {
     }
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
-    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr);
     delete s;
 }
 
@@ -1541,11 +1613,11 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
-    K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.lds_stack_off = lds_image_bytes_for(scene, lds);
+    K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : tn.general));
+        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : (scene->ordered ? tn.ordered_general : tn.general)));
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
     }
 
@@ -1642,7 +1714,9 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     for (const auto &t : cs.textures)
         if (t.kind != RT_TEXTURE_SOLID) s->features |= F_TEXTURES;
     s->ordered = cs.ordered;
-    s->o_root = cs.ordered_root;
+    // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
+    s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
+    s->n_oseq = (uint32_t)cs.oseq.size();
     s->o_stack = cs.ordered_stack;
     // Node tables (load_node / load_opair): threaded records as two 16-byte halves, ordered records as six 16-byte plane
     // tables and an 8-byte reference table.  LDS image = node tables | spheres | quads; every LDS level copies a prefix.
@@ -1731,7 +1805,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     }
 
     int rc = RT_OK;
-    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
+    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->oseq, cs.oseq)) != RT_OK ||
+        (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
         (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
         (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
         (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
@@ -1853,6 +1928,7 @@ int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max) {
     Tuning &t = tuning();
     if (ordered >= 0) t.ordered = ordered;
     if (leaf_max > 0) t.ordered_options.leaf_max = (uint32_t)leaf_max < OREF_MAX_LEAF ? (uint32_t)leaf_max : OREF_MAX_LEAF;
+    else if (leaf_max == 0) t.ordered_options.leaf_max = OrderedOptions().leaf_max;
     return RT_OK;
 }
 
@@ -1868,7 +1944,17 @@ int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) {
         return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_ordered_layout: ") + e.what());
     }
     io->ordered = cs.ordered ? 1u : 0u;
-    io->root = cs.ordered_root;
+    io->root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0u;
+    io->n_steps = (int64_t)cs.oseq.size();
+    if (io->steps) {
+        if (io->cap_steps < io->n_steps) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: steps buffer too small");
+        if (io->n_steps) memcpy(io->steps, cs.oseq.data(), cs.oseq.size() * sizeof(OSeq));
+    }
+    io->n_media = (int64_t)cs.media.size();
+    if (io->media) {
+        if (io->cap_media < io->n_media) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: media buffer too small");
+        for (size_t i = 0; i < cs.media.size(); ++i) io->media[i] = cs.media[i].first_node;
+    }
     io->stack_entries = cs.ordered_stack;
     io->n_nodes = (int64_t)cs.onodes.size(); io->n_spheres = (int64_t)cs.spheres.size();
     io->n_quads = (int64_t)cs.quads.size(); io->n_instances = (int64_t)cs.instances.size();

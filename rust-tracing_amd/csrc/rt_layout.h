@@ -67,6 +67,18 @@ struct alignas(64) ONode {
 };
 static_assert(sizeof(ONode) == 64, "ONode must be 64 bytes");
 constexpr uint32_t ORDERED_MAX_STACK = 32; // per-lane stack entries the kernel provides at most
+// The world frame of an ordered scene is a sequence of these, walked in order (rt_ordered.hpp): a tree over a run of
+// medium-free objects, or a ConstantMedium — bounded by one Sphere (solved in place) or by a subtree with its own tree.
+enum OrderedSeqKind : uint32_t { OSEQ_TREE = 0, OSEQ_MEDIUM_SPHERE = 1, OSEQ_MEDIUM = 2 };
+struct alignas(16) OSeq {
+    uint32_t kind;
+    uint32_t a;     // TREE: root record; media: medium index
+    uint32_t b;     // MEDIUM: root record of the boundary's tree
+    uint32_t _pad;
+    float box[6];   // (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi), f32 rounded outward: what the step can touch
+    uint32_t _pad2[2];
+};
+static_assert(sizeof(OSeq) == 48, "OSeq must be 48 bytes");
 
 // 64 bytes
 struct alignas(64) Sphere {

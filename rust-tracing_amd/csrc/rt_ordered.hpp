@@ -7,8 +7,14 @@
 // tree (random axis, median split, src/bvh.rs:31-66) must be walked left child first to reproduce its tie
 // handling; with ties settled explicitly by `seq` (rt_kernel.hip "ties") neither the tree nor the order matters,
 // and a surface-area-heuristic tree walked nearest child first needs a fraction of the box tests.
-// A ConstantMedium breaks this (its hit() consumes a draw only if the walk reaches it, src/constant_medium.rs:33-61):
-// such scenes keep the threaded layout.
+// A ConstantMedium breaks this only locally: its hit() consumes a draw iff its boundary is crossed before the closest hit
+// found SO FAR in the scan (src/constant_medium.rs:33-61), so what matters is which primitives come before it in scan
+// order, not how they are searched.  The world frame therefore becomes a SEQUENCE: maximal runs of medium-free objects
+// (each searched through a tree of its own, in any order) alternating with the media, in the reference's scan order;
+// a medium's boundary is again a closest-hit query over a medium-free subtree and gets its own tree.  (Whether the
+// reference would have culled the medium by one of its ancestors' boxes does not matter: those boxes contain the
+// boundary, and a ray that cannot reach the boundary before the current closest hit draws nothing either way.)
+// Only a medium inside a Translate / RotateY frame or inside another medium's boundary keeps the threaded layout.
 #pragma once
 #include "rt_compile.hpp"
 #include <algorithm>
@@ -22,29 +28,30 @@ struct OrderedOptions {
     double cost_sphere = 1.6;     // ... against one Sphere::hit,
     double cost_quad = 0.8;       // one Quad::hit (most end at the plane test),
     double cost_instance = 6.0;   // and one frame change plus the walk inside
-    uint32_t world_depth = 22;    // inner records on a root-to-leaf path at most: world frame
-    uint32_t frame_depth = 8;     // ... and inside a frame (the kernel's stack holds ORDERED_MAX_STACK entries in all)
+    uint32_t world_depth = 24;    // inner records on a root-to-leaf path at most ...
+    uint32_t frame_slack = 4;     // ... and at most this many more than an even split of the tree's items needs
+                                  // (the kernel's stack holds ORDERED_MAX_STACK entries in all, frames below included)
 };
 
 class OrderedBuilder {
   public:
     OrderedBuilder(CompiledScene &cs, const OrderedOptions &opt) : cs_(cs), opt_(opt) {}
 
-    // false: the scene must keep the threaded layout (a medium, or a tree too deep for the stack)
+    // false: the scene must keep the threaded layout (a medium inside a frame, or a tree too deep for the stack)
     bool run() {
-        if (!cs_.media.empty()) return false;
         if (cs_.spheres.size() > OREF_INDEX_MASK || cs_.quads.size() > OREF_INDEX_MASK) return false;
         if (!collect()) return false;
-        const size_t n_inst = cs_.instances.size();
-        need_.assign(n_inst + 1, 0);
-        bound_.assign(n_inst + 1, Bound());
-        root_.assign(n_inst + 1, 0);
-        // innermost frames first: an instance's box in its parent's frame comes from the tree built for it
-        for (size_t f = n_inst + 1; f-- > 0;) {
+        const size_t n_frames = frames_.size();
+        need_.assign(n_frames, 0);
+        bound_.assign(n_frames, Bound());
+        root_.assign(n_frames, 0);
+        // innermost frames first (a frame is always created after the one that refers to it): an instance's box in its
+        // parent's frame comes from the tree built for it
+        for (size_t f = n_frames; f-- > 0;) {
             std::vector<Item> &items = frames_[f];
             for (Item &it : items)
                 if (it.kind == OK_INSTANCE) {
-                    Bound b = instance_bound(cs_.instances[it.index], bound_[it.index + 1]);
+                    Bound b = instance_bound(cs_.instances[it.index], bound_[frame_of_inst_[it.index]]);
                     if (!b.empty())
                         for (int ax = 0; ax < 3; ++ax) pad_axis(b.lo[ax], b.hi[ax]);
                     it.b = b;
@@ -57,13 +64,52 @@ class OrderedBuilder {
             }
             build_frame(f);
         }
-        if (need_[0] > ORDERED_MAX_STACK) return false;
-        for (size_t i = 0; i < n_inst; ++i) cs_.instances[i].root = root_[i + 1];
+        // the world frame's sequence: trees and media in scan order
+        uint32_t need = 1;
+        std::vector<OSeq> seq;
+        for (const SeqItem &si : sequence_) {
+            OSeq o{};
+            o.kind = si.kind;
+            Bound b;
+            if (si.kind == OSEQ_TREE) {
+                if (frames_[si.frame].empty()) continue;
+                o.a = root_[si.frame];
+                need = std::max(need, need_[si.frame]);
+                b = bound_[si.frame];
+            } else if (si.kind == OSEQ_MEDIUM_SPHERE) {
+                o.a = si.medium;
+                // the boundary sphere is in no leaf: it moves to the end of the (reordered) sphere table
+                const uint32_t old_index = cs_.media[si.medium].first_node;
+                b = sphere_bound(cs_.spheres[old_index]);
+                cs_.media[si.medium].first_node = (uint32_t)new_spheres_.size();
+                new_spheres_.push_back(cs_.spheres[old_index]);
+            } else {
+                if (frames_[si.frame].empty()) continue; // a boundary without geometry: the medium can never be hit
+                o.a = si.medium;
+                o.b = root_[si.frame];
+                need = std::max(need, need_[si.frame]);
+                b = bound_[si.frame];
+            }
+            for (int ax = 0; ax < 3; ++ax) {
+                pad_axis(b.lo[ax], b.hi[ax]);
+                o.box[2 * ax] = round_down(b.lo[ax]);
+                o.box[2 * ax + 1] = round_up(b.hi[ax]);
+            }
+            seq.push_back(o);
+        }
+        if (need > ORDERED_MAX_STACK) return false;
+        if (seq.empty()) { // nothing can be hit: one tree whose root has two empty children
+            OSeq o{};
+            o.kind = OSEQ_TREE;
+            o.a = alloc_node();
+            seq.push_back(o);
+        }
+        for (size_t i = 0; i < cs_.instances.size(); ++i) cs_.instances[i].root = root_[frame_of_inst_[i]];
         cs_.spheres.swap(new_spheres_);
         cs_.quads.swap(new_quads_);
         cs_.onodes.swap(nodes_);
-        cs_.ordered_root = root_[0];
-        cs_.ordered_stack = need_[0] ? need_[0] : 1u;
+        cs_.oseq.swap(seq);
+        cs_.ordered_stack = need;
         cs_.ordered = true;
         return true;
     }
@@ -84,20 +130,41 @@ class OrderedBuilder {
 
     CompiledScene &cs_;
     OrderedOptions opt_;
-    std::vector<std::vector<Item>> frames_; // [0] world, [1 + i] instance i
+    std::vector<std::vector<Item>> frames_; // one per tree: runs of the world frame, instances, medium boundaries
     std::vector<uint32_t> need_, root_;
     std::vector<Bound> bound_;
     std::vector<ONode> nodes_;
     std::vector<Sphere> new_spheres_;
     std::vector<Quad> new_quads_;
 
-    // the threaded records list every primitive and frame change in the reference's scan order
+    struct SeqItem {
+        uint32_t kind, frame, medium;
+    };
+    std::vector<SeqItem> sequence_;
+    std::vector<uint32_t> frame_of_inst_;
+
+    uint32_t new_frame() {
+        frames_.emplace_back();
+        return (uint32_t)frames_.size() - 1u;
+    }
+    // The threaded records list every primitive, frame change and medium in the reference's scan order.
     bool collect() {
-        frames_.assign(cs_.instances.size() + 1, {});
-        std::vector<uint32_t> open{0u};
+        frames_.clear();
+        sequence_.clear();
+        frame_of_inst_.assign(cs_.instances.size(), 0u);
+        enum Where : uint32_t { WORLD, INSTANCE, BOUNDARY };
+        struct Open { uint32_t frame, where; };
+        const uint32_t NO_FRAME = 0xffffffffu;
+        std::vector<Open> open{{NO_FRAME, WORLD}}; // the world's current run of medium-free objects gets its frame lazily
+        auto current = [&]() -> std::vector<Item> & {
+            if (open.back().frame == NO_FRAME) {
+                open.back().frame = new_frame();
+                sequence_.push_back({OSEQ_TREE, open.back().frame, 0u});
+            }
+            return frames_[open.back().frame];
+        };
         for (const Node &n : cs_.nodes) {
             const uint32_t kind = n.kind & NODE_KIND_MASK;
-            std::vector<Item> &cur = frames_[open.back()];
             if (kind == NK_SPHERES || kind == NK_QUADS) {
                 for (uint32_t i = 0; i < n.b; ++i) {
                     Item it{};
@@ -109,15 +176,31 @@ class OrderedBuilder {
                         if (!std::isfinite(it.b.lo[ax]) || !std::isfinite(it.b.hi[ax])) return false; // not a shape a box can hold
                         pad_axis(it.b.lo[ax], it.b.hi[ax]);
                     }
-                    cur.push_back(it);
+                    current().push_back(it);
                 }
             } else if (kind == NK_INST_ENTER) {
                 Item it{};
                 it.kind = OK_INSTANCE;
                 it.index = n.a;
-                cur.push_back(it);
-                open.push_back(n.a + 1u);
+                current().push_back(it);
+                frame_of_inst_[n.a] = new_frame();
+                open.push_back({frame_of_inst_[n.a], INSTANCE});
             } else if (kind == NK_INST_EXIT) {
+                open.pop_back();
+            } else if (kind == NK_MEDIUM_SPHERE || kind == NK_MEDIUM_ENTER) {
+                if (open.size() != 1) return false; // a medium inside a frame or a boundary: threaded layout
+                open.back().frame = NO_FRAME;       // the run of medium-free objects ends here
+                if (kind == NK_MEDIUM_SPHERE) {
+                    const Sphere &sp = cs_.spheres[cs_.media[n.a].first_node];
+                    if (!std::isfinite(sp.radius) || !std::isfinite(sp.center[0]) || !std::isfinite(sp.center[1]) || !std::isfinite(sp.center[2]))
+                        return false;
+                    sequence_.push_back({OSEQ_MEDIUM_SPHERE, 0u, n.a});
+                } else {
+                    const uint32_t f = new_frame();
+                    sequence_.push_back({OSEQ_MEDIUM, f, n.a});
+                    open.push_back({f, BOUNDARY});
+                }
+            } else if (kind == NK_MEDIUM_EXIT) {
                 open.pop_back();
             } else if (kind != NK_INNER) {
                 return false;
@@ -157,7 +240,13 @@ class OrderedBuilder {
 
     void build_frame(size_t f) {
         std::vector<Item> &items = frames_[f];
-        const uint32_t budget = f == 0 ? opt_.world_depth : opt_.frame_depth;
+        // a frame's own depth, the exit marker and the deepest frame below it share the ORDERED_MAX_STACK stack entries
+        uint32_t below = 0;
+        for (const Item &it : items)
+            if (it.kind == OK_INSTANCE) below = std::max(below, 1u + need_[frame_of_inst_[it.index]]);
+        uint32_t budget = std::min(opt_.world_depth, levels_for(items.size()) + opt_.frame_slack);
+        if (below >= ORDERED_MAX_STACK) { need_[f] = ORDERED_MAX_STACK + 1; return; }
+        budget = std::min(budget, ORDERED_MAX_STACK - below);
         if (items.empty()) { // nothing to hit: a record with two empty children
             root_[f] = alloc_node();
             need_[f] = 1;
@@ -181,7 +270,7 @@ class OrderedBuilder {
         const Item &first = items[lo];
         if (first.kind == OK_INSTANCE) {
             out.ref = (OK_INSTANCE << OREF_KIND_SHIFT) | first.index;
-            out.need = 1u + need_[first.index + 1]; // the frame-exit marker, then the walk inside
+            out.need = 1u + need_[frame_of_inst_[first.index]]; // the frame-exit marker, then the walk inside
             return out;
         }
         // primitives of a leaf sit next to each other in the table, in scan order

@@ -19,6 +19,7 @@ class CustomScene:
     def __init__(self, camera_from: "rt.HostScene", spp=4, depth=6, background=None):
         self.spheres, self.quads, self.lists, self.items = [], [], [], []
         self.translates, self.rotates, self.materials, self.textures = [], [], [], []
+        self.media = []
         self.camera = rt.Camera.from_buffer_copy(camera_from.camera)
         self.camera.samples_per_pixel = spp
         self.camera.max_depth = depth
@@ -44,6 +45,10 @@ class CustomScene:
 
     def metal(self, r, g, b, fuzz):
         self.materials.append(rt.Material(kind=rt.RT_MATERIAL_METAL, texture=-1, albedo=_v(r, g, b), fuzz=fuzz))
+        return len(self.materials) - 1
+
+    def isotropic(self, r, g, b):
+        self.materials.append(rt.Material(kind=rt.RT_MATERIAL_ISOTROPIC, texture=self.solid(r, g, b)))
         return len(self.materials) - 1
 
     def dielectric(self, ir):
@@ -81,6 +86,11 @@ class CustomScene:
         self.rotates.append(rt.RotateY(object=ref, sin_theta=math.sin(th), cos_theta=math.cos(th)))
         return rt.Ref(rt.RT_HITTABLE_ROTATE_Y, len(self.rotates) - 1)
 
+    def medium(self, boundary, density, r, g, b):
+        # ConstantMedium::new (src/constant_medium.rs:21-30): neg_inv_density = -1 / density, phase = Isotropic(colour)
+        self.media.append(rt.ConstantMedium(boundary=boundary, neg_inv_density=-1.0 / density, phase_material=self.isotropic(r, g, b)))
+        return rt.Ref(rt.RT_HITTABLE_CONSTANT_MEDIUM, len(self.media) - 1)
+
     def finish(self, world: "rt.Ref"):
         def arr(kind, values):
             a = (kind * max(1, len(values)))(*values)
@@ -88,7 +98,8 @@ class CustomScene:
 
         self._keep = dict(spheres=arr(rt.Sphere, self.spheres), quads=arr(rt.Quad, self.quads), lists=arr(rt.List, self.lists),
                           items=arr(rt.Ref, self.items), translates=arr(rt.Translate, self.translates),
-                          rotates=arr(rt.RotateY, self.rotates), materials=arr(rt.Material, self.materials),
+                          rotates=arr(rt.RotateY, self.rotates), media=arr(rt.ConstantMedium, self.media),
+                          materials=arr(rt.Material, self.materials),
                           textures=arr(rt.Texture, self.textures))
         k = self._keep
         d = rt.SceneDesc()
@@ -100,6 +111,7 @@ class CustomScene:
         d.n_list_items, d.list_items = len(self.items), k["items"]
         d.n_translates, d.translates = len(self.translates), k["translates"]
         d.n_rotates, d.rotates = len(self.rotates), k["rotates"]
+        d.n_media, d.media = len(self.media), k["media"]
         d.n_materials, d.materials = len(self.materials), k["materials"]
         d.n_textures, d.textures = len(self.textures), k["textures"]
         self.desc = d
@@ -157,4 +169,37 @@ def many_spheres_scene(camera_from, n, seed=5):
         r = rnd.uniform(0.05, 0.25)
         y = -3.0 + r + rnd.choice([0.0, 0.0, rnd.uniform(0, 3)])
         items.append(s.sphere((x, y, z), r, rnd.choice(mats)))
+    return s.finish(s.list(items))
+
+
+def media_scene(camera_from, order=0, nested=False):
+    """Participating media in every position of the scan: bounded by a sphere, by a rotated and shifted cube, by a bare
+    list of quads; first, last, next to each other; overlapping each other and solid objects.  nested: one of them sits
+    inside a Translate (a case the ordered layout leaves to the reference-order walk)."""
+    s = CustomScene(camera_from, spp=4, depth=8, background=(0.7, 0.8, 1.0))
+    red, green, white = s.lambertian(0.9, 0.2, 0.2), s.lambertian(0.2, 0.9, 0.2), s.lambertian(0.8, 0.8, 0.8)
+    mirror, glass, lamp = s.metal(0.8, 0.8, 0.6, 0.05), s.dielectric(1.5), s.light(5, 5, 5)
+
+    def cube(lo, hi, m):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
+        return s.list([s.quad((x0, y0, z1), (dx, 0, 0), (0, dy, 0), m), s.quad((x1, y0, z1), (0, 0, -dz), (0, dy, 0), m),
+                       s.quad((x1, y0, z0), (-dx, 0, 0), (0, dy, 0), m), s.quad((x0, y0, z0), (0, 0, dz), (0, dy, 0), m),
+                       s.quad((x0, y1, z1), (dx, 0, 0), (0, 0, -dz), m), s.quad((x0, y0, z0), (dx, 0, 0), (0, 0, dz), m)])
+
+    floor = s.quad((-4, -2, -4), (8, 0, 0), (0, 0, 8), white)
+    wall = s.quad((-4, -2, -3), (8, 0, 0), (0, 6, 0), red)
+    light = s.quad((-1, 3.5, -1), (2, 0, 0), (0, 0, 2), lamp)
+    ball, ball2 = s.sphere((-1.5, -1.0, 0.5), 1.0, glass), s.sphere((1.8, -1.2, 1.0), 0.8, mirror)
+    fog_ball = s.medium(s.sphere((-1.5, -1.0, 0.5), 0.95, glass), 2.0, 0.2, 0.4, 0.9)        # inside the glass ball
+    smoke = s.medium(s.translate(s.rotate_y(cube((-0.7, -0.7, -0.7), (0.7, 0.7, 0.7), white), 25.0), (0.5, -1.0, -1.0)), 1.5, 0.05, 0.05, 0.05)
+    haze = s.medium(cube((-3.5, -2.0, -2.5), (3.5, 0.0, 3.0), white), 0.15, 1.0, 1.0, 1.0)   # a bare list as the boundary
+    mist = s.medium(s.sphere((0, 0, 0), 30.0, white), 0.01, 0.9, 0.9, 0.9)                    # everything is inside it
+    if nested:
+        smoke = s.translate(s.list([smoke]), (0.0, 0.5, 0.0))
+    items = [mist, floor, ball, fog_ball, wall, smoke, haze, light, ball2, s.sphere((1.8, -1.2, 1.0), 0.8, green)]
+    if order == 1:
+        items = items[::-1]
+    elif order == 2:
+        items = items[1::2] + items[0::2]
     return s.finish(s.list(items))

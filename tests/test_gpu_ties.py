@@ -28,7 +28,7 @@ def check(rt, oracle, scene, what):
                 bad = np.flatnonzero(bits(got) != bits(want))
                 assert bad.size == 0, f"{what}: ordered={ordered} leaf={leaf}: {bad.size} of {want.size} values differ, first at {bad[:4]}"
     finally:
-        lib.rt_debug_set_traversal(1, 4)
+        lib.rt_debug_set_traversal(1, 0)
 
 
 @pytest.mark.parametrize("order", [0, 1, 2])
@@ -43,7 +43,7 @@ def test_single_primitive_and_empty_frame(rt, oracle, gpu):
     check(rt, oracle, custom_scenes.empty_frame_scene(cam), "empty frame")
 
 
-@pytest.mark.parametrize("name", [n for n in scene_cases.CASES if "smoke" not in n and "final" not in n])
+@pytest.mark.parametrize("name", list(scene_cases.CASES))
 def test_both_traversals_match_the_oracle(rt, oracle, gpu, name):
     """test_gpu_parity checks the default walk; here every scene that has two walks is rendered with each."""
     hs = scene_cases.build(rt, name)
@@ -60,3 +60,24 @@ def test_scenes_larger_than_the_lds(rt, oracle, gpu, n, lds_nodes_expected):
     assert st["ordered"] == 1 and st["n_spheres"] == n + 1
     assert (st["lds_nodes"] > 0) == lds_nodes_expected and st["lds_bytes"] < 160 * 1024
     check(rt, oracle, scene, f"{n} spheres")
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_media_between_other_objects(rt, oracle, gpu, order):
+    """Media bounded by a sphere, by a rotated cube and by a bare list, first / last / next to each other in the scan:
+    each draws iff its boundary is crossed before the closest hit found so far in the reference's scan."""
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.media_scene(cam, order)
+    assert rt.DeviceScene(scene).stats()["ordered"] == 1
+    check(rt, oracle, scene, f"media scene, order {order}")
+
+
+def test_medium_inside_a_frame_keeps_the_reference_walk(rt, oracle, gpu):
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.media_scene(cam, 0, nested=True)
+    lib = rt.amd_lib()
+    assert rt.DeviceScene(scene).stats()["ordered"] == 0
+    params = rt.render_params(seed=3)
+    want = oracle.render(scene, params)
+    got = rt.DeviceScene(scene).render(params)
+    assert (bits(got) == bits(want)).all()

@@ -77,24 +77,56 @@ def walk(lay, node, seen, depth_left):
     return lo_all, hi_all, need + 1
 
 
-@pytest.mark.parametrize("name", [n for n in scene_cases.CASES if "smoke" not in n and "final" not in n])
+def walk_steps(lay, seen):
+    """Every step of the world frame's sequence: its tree(s) hold their primitives inside the step's box.  Returns the
+    deepest stack need."""
+    need = 0
+    for step in lay["steps"]:
+        kind, a, b = int(step[0]), int(step[1]), int(step[2])
+        box = f32_box(step[4:10])
+        if kind == 1:  # a medium bounded by one sphere: that sphere is in no leaf
+            index = int(lay["media"][a])
+            seen.add((KIND_SPHERES, index))
+            lo, hi = prim_bound(lay, KIND_SPHERES, index)
+            sub = 0
+        else:
+            lo, hi, sub = walk(lay, a if kind == 0 else b, seen, 64)
+        assert (box[:, 0] <= lo).all() and (box[:, 1] >= hi).all(), (kind, box, lo, hi)
+        need = max(need, sub)
+    return need
+
+
+@pytest.mark.parametrize("name", list(scene_cases.CASES))
 def test_tree_holds_every_primitive_once_inside_its_boxes(rt, name):
     hs = scene_cases.build(rt, name)
     lay = rt.debug_ordered_layout(hs)
     assert lay["ordered"]
     seen = set()
-    _, _, need = walk(lay, lay["root"], seen, 64)
+    need = walk_steps(lay, seen)
     assert len(seen) == len(lay["spheres"]) + len(lay["quads"])
     assert need <= lay["stack_entries"] <= 32
+    assert int(lay["steps"][0][0]) != 0 or lay["root"] == int(lay["steps"][0][1])
     # seq is a numbering of all primitives in the reference's scan order: a permutation of 0..n-1
     seqs = np.concatenate([lay["spheres"][:, 7], lay["quads"][:, 9]])
     assert sorted(seqs.astype(int)) == list(range(len(seqs)))
 
 
-def test_scenes_with_a_medium_keep_the_reference_order(rt):
-    for name in ("cornell_smoke_64x64_16spp", "c4_final_scene_64x64_8spp_d40"):
-        lay = rt.debug_ordered_layout(scene_cases.build(rt, name))
-        assert not lay["ordered"] and len(lay["nodes"]) == 0
+def test_scenes_with_media_become_sequences_in_scan_order(rt):
+    """cornell_smoke: walls, then the two smoke boxes (each with a boundary tree), then the wall added after them;
+    final_scene: whatever order the top-level BVH (built with scene_seed 1) scans its eleven leaves in."""
+    lay = rt.debug_ordered_layout(scene_cases.build(rt, "cornell_smoke_64x64_16spp"))
+    assert lay["ordered"] and [int(k) for k in lay["steps"][:, 0]] == [0, 2, 2, 0]
+    lay = rt.debug_ordered_layout(scene_cases.build(rt, "c4_final_scene_64x64_8spp_d40"))
+    kinds = [int(k) for k in lay["steps"][:, 0]]
+    assert lay["ordered"] and kinds.count(1) == 2 and kinds.count(2) == 0 and 1 <= kinds.count(0) <= 3
+    assert len(lay["spheres"]) == 1008 and len(lay["quads"]) == 2401
+
+
+def test_a_medium_inside_a_frame_is_left_to_the_reference_walk(rt):
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    assert rt.debug_ordered_layout(custom_scenes.media_scene(cam, 0))["ordered"]
+    lay = rt.debug_ordered_layout(custom_scenes.media_scene(cam, 0, nested=True))
+    assert not lay["ordered"] and len(lay["nodes"]) == 0
 
 
 def test_random_spheres_tree_is_shallow_and_tight(rt):
@@ -117,11 +149,12 @@ def test_random_spheres_tree_is_shallow_and_tight(rt):
 
 def test_hand_made_scenes_compile(rt):
     cam = scene_cases.build(rt, "quads_64x64_8spp")
-    for scene in (custom_scenes.tie_scene(cam, 0), custom_scenes.single_sphere_scene(cam), custom_scenes.empty_frame_scene(cam)):
+    for scene in (custom_scenes.tie_scene(cam, 0), custom_scenes.single_sphere_scene(cam), custom_scenes.empty_frame_scene(cam),
+                  custom_scenes.media_scene(cam, 0), custom_scenes.media_scene(cam, 1), custom_scenes.media_scene(cam, 2)):
         lay = rt.debug_ordered_layout(scene)
         assert lay["ordered"]
         seen = set()
-        walk(lay, lay["root"], seen, 64)
+        walk_steps(lay, seen)
         assert len(seen) == len(lay["spheres"]) + len(lay["quads"])
     lay = rt.debug_ordered_layout(custom_scenes.single_sphere_scene(cam))
     assert len(lay["nodes"]) == 1 and int(lay["nodes"][0][13]) >> 29 == KIND_EMPTY  # a root record with one child

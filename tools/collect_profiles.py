@@ -11,9 +11,9 @@ tag = sys.argv[1]
 
 
 def one(pattern):
-    hits = glob.glob(str(SRC / pattern))
-    assert len(hits) == 1, (pattern, hits)
-    return Path(hits[0])
+    hits = sorted(glob.glob(str(SRC / pattern)), key=lambda f: Path(f).stat().st_mtime)
+    assert hits, pattern
+    return Path(hits[-1])  # (gpurun merges into gpurun_out/ without clearing it: take the latest run's file)
 
 
 def counters(run, kernel_prefix="void (anonymous namespace)::path_kernel<false"):
