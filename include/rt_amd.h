@@ -340,8 +340,9 @@ int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
  * (kind << 29 | (count - 1) << 26 | index; kind 0 record, 1 spheres, 2 quads, 3 instance, 7 empty), 2 unused.
  * spheres: 9 doubles = center, radius, center_vec, seq, is_moving.  quads: 10 = q, u, v, seq.
  * instances: 8 = offset, sin, cos, parent, flags (1 translate, 2 rotate), root record.
- * steps: the world frame's sequence, 12 words per step = kind (0 tree, 1 medium bounded by one sphere, 2 medium with a
- * boundary tree), a (tree: root record; medium: its index), b (boundary tree's root), unused, box as 6 floats, 2 unused.
+ * steps: the world frame's sequence, 28 words per step = kind (0 tree, 1 medium bounded by one sphere, 2 medium with a
+ * boundary tree), a (tree: root record; medium: its index), b (boundary tree's root), moving, box as 6 floats, 2 unused,
+ * then as doubles: the boundary sphere's center (3), radius, center_vec (3), and the medium's neg_inv_density.
  * media: per medium, the index of its boundary sphere (kind 1 steps). `root` is the first step's tree. */
 typedef struct rt_debug_ordered {
     int64_t cap_nodes, cap_spheres, cap_quads, cap_instances, cap_steps, cap_media;

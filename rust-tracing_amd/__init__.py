@@ -246,7 +246,7 @@ def debug_ordered_layout(host_scene) -> dict:
     nodes = np.zeros((max(io.n_nodes, 1), 16), dtype=np.uint32)
     spheres = np.zeros((max(io.n_spheres, 1), 9)); quads = np.zeros((max(io.n_quads, 1), 10))
     insts = np.zeros((max(io.n_instances, 1), 8))
-    steps = np.zeros((max(io.n_steps, 1), 12), dtype=np.uint32); media = np.zeros(max(io.n_media, 1), dtype=np.uint32)
+    steps = np.zeros((max(io.n_steps, 1), 28), dtype=np.uint32); media = np.zeros(max(io.n_media, 1), dtype=np.uint32)
     io.cap_nodes, io.cap_spheres, io.cap_quads, io.cap_instances = len(nodes), len(spheres), len(quads), len(insts)
     io.cap_steps, io.cap_media = len(steps), len(media)
     io.nodes, io.spheres, io.quads, io.instances = (a.ctypes.data for a in (nodes, spheres, quads, insts))

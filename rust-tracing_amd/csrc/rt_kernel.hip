@@ -87,6 +87,7 @@ struct KParams {
     uint32_t n_oseq;
     uint32_t o_root;
     uint32_t lds_stack_off;
+    uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)
     uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
 };
 
@@ -443,6 +444,14 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         for (uint32_t k = threadIdx.x; k < P.lds_image_bytes / 16u; k += THREADS) dst[k] = P.lds_image[k];
         __syncthreads();
     }
+    // the world frame's sequence (scenes with media) sits behind the stacks
+    const OSeq *const seq_tab = reinterpret_cast<const OSeq *>(lds_raw + P.lds_seq_off);
+    if constexpr (ORDERED && HAS_MEDIA) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw + P.lds_seq_off);
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.oseq);
+        for (uint32_t k = threadIdx.x; k < P.n_oseq * (uint32_t)(sizeof(OSeq) / 16u); k += THREADS) dst[k] = src[k];
+        __syncthreads();
+    }
     const Sphere *const sphere_tab = LDS >= 2 ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
     const Quad *const quad_tab = LDS == 3 ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
     // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree) is parked in global
@@ -551,17 +560,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // ---- ConstantMedium::hit (src/constant_medium.rs:33-71), shared by both walks ----
     // a medium bounded by one Sphere: the two boundary.hit calls solve the same quadratic (src/sphere.rs:58-83), first over
     // (-inf, inf), then over (t1 + 0.0001, inf)
-    auto medium_sphere_hit = [&](uint32_t na) {
-        // ConstantMedium::hit with a Sphere boundary (src/constant_medium.rs:33-71): the two boundary.hit calls
-        // solve the same quadratic (src/sphere.rs:58-83), first over (-inf, inf), then over (t1 + 0.0001, inf)
+    auto medium_sphere_hit = [&](uint32_t na, V3 center, V3 center_vec, bool moving, double radius, double neg_inv_density) {
         if (COUNT) { cn.medium_visits++; cn.sphere_tests++; }
-        const Medium md = P.media[na];
-        const Sphere *s = &sphere_tab[md.first_node];
-        V3 center = ld3(s->center);
-        if ((s->seq_moving & 1u)) center = center + ld3(s->center_vec) * time;
+        if (moving) center = center + center_vec * time;
         const V3 oc = o - center;
         const double half_b = dot(oc, d);
-        const double c = len2(oc) - s->radius * s->radius;
+        const double c = len2(oc) - radius * radius;
         const double discriminant = half_b * half_b - a * c;
         if (!(discriminant < 0.0)) {
             const double sqrtd = __builtin_sqrt(discriminant);
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         const double ray_length = __builtin_sqrt(len2(d));
                         const double distance_inside_boundary = (h2 - h1) * ray_length;
                         if (COUNT) cn.rng_draws++;
-                        const double hit_distance = md.neg_inv_density * rt_log(rng.random());
+                        const double hit_distance = neg_inv_density * rt_log(rng.random());
                         if (hit_distance <= distance_inside_boundary) {
                             best_t = h1 + hit_distance / ray_length;
                             best_prim = PRIM_MEDIUM | na;
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         }
     };
     // a boundary query (mode 1 or 2) of medium `na` has just ended; true: the second query has to run (interval set)
-    auto medium_boundary_done = [&](uint32_t na) -> bool {
+    auto medium_boundary_done = [&](uint32_t na, double neg_inv_density) -> bool {
         bool again = false;
         const bool sub_hit = (mode & 0x100u) != 0;
         if ((mode & 3u) == 1) {
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 const double ray_length = __builtin_sqrt(len2(d));
                 const double distance_inside_boundary = (h2 - h1) * ray_length;
                 if (COUNT) cn.rng_draws++;
-                const double hit_distance = P.media[na].neg_inv_density * rt_log(rng.random());
+                const double hit_distance = neg_inv_density * rt_log(rng.random());
                 if (hit_distance <= distance_inside_boundary) {
                     best_t = h1 + hit_distance / ray_length;
                     best_prim = PRIM_MEDIUM | na;
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             // nothing closer, a medium there draws nothing (src/constant_medium.rs:40-44: t1 >= t2)
             stage = ST_SHADE;
             while (seq_pc < P.n_oseq) {
-                const OSeq *rec = &P.oseq[seq_pc];
+                const OSeq *rec = &seq_tab[seq_pc];
                 seq_pc++;
                 float enter;
                 bool miss0, miss1;
@@ -645,7 +649,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 if (rec->kind == OSEQ_TREE) {
                     node = rec->a; sp = 0; stage = ST_BOX;
                 } else if (rec->kind == OSEQ_MEDIUM_SPHERE) {
-                    medium_sphere_hit(rec->a); // (may lower cur_tmax: the following steps are tested against it)
+                    medium_sphere_hit(rec->a, ld3(rec->center), ld3(rec->center_vec), rec->moving != 0, rec->radius, rec->neg_inv_density);
+                    // (it may have lowered cur_tmax: the following steps are tested against that)
                     continue;
                 } else { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
                     if (COUNT) cn.medium_visits++;
@@ -851,8 +856,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // ---- the world frame's sequence (rt_layout.h OSeq): a tree or a boundary query has ended ----
                     bool again = false;
                     if ((mode & 3u) != 0) { // a boundary query of the medium at the previous step
-                        const OSeq *rec = &P.oseq[seq_pc - 1u];
-                        again = medium_boundary_done(rec->a);
+                        const OSeq *rec = &seq_tab[seq_pc - 1u];
+                        again = medium_boundary_done(rec->a, rec->neg_inv_density);
                         if (again) { node = rec->b; sp = 0; stage = ST_BOX; }
                     }
                     if (!again) seq_advance();
@@ -911,10 +916,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     cur_tmax = INF;
                     node = node + 1;
                 } else if (HAS_MEDIA && kind == NK_MEDIUM_SPHERE) {
-                    medium_sphere_hit(na);
+                    const Medium md = P.media[na];
+                    const Sphere *s = &sphere_tab[md.first_node];
+                    medium_sphere_hit(na, ld3(s->center), ld3(s->center_vec), (s->seq_moving & 1u) != 0, s->radius, md.neg_inv_density);
                     node = nd.skip;
                 } else if (HAS_MEDIA) { // NK_MEDIUM_EXIT
-                    if (medium_boundary_done(na)) node = P.media[na].first_node;
+                    if (medium_boundary_done(na, P.media[na].neg_inv_density)) node = P.media[na].first_node;
                     else node = node + 1;
                 }
                 if (kind == NK_INST_ENTER || kind == NK_INST_EXIT) {
@@ -1465,7 +1472,8 @@ size_t stack_bytes(const rt_scene *s, int lds) {
     return (size_t)s->o_stack * (lds ? (size_t)LDS_THREADS * 2u : (size_t)GLOBAL_THREADS * 4u);
 }
 size_t prof_bytes(int lds) { return (size_t)((lds ? LDS_THREADS : GLOBAL_THREADS) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
-size_t prof_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 7u) & ~(size_t)7u; }
+size_t seq_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 15u) & ~(size_t)15u; }
+size_t prof_offset(const rt_scene *s, int lds) { return seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u); }
 size_t dynamic_lds_bytes(const rt_scene *s, int lds, bool counted) {
     return prof_offset(s, lds) + (counted ? prof_bytes(lds) : 0);
 }
@@ -1614,6 +1622,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
+    K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
@@ -1753,7 +1762,8 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
         const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
         const size_t stack = stack_bytes(s, 1);
         // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
-        const size_t budget = LDS_BUDGET_BYTES - 4096; // (the instrumented kernels keep their profile rows behind the stacks)
+        // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
+        const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
         s->lds_level = total + stack <= budget ? 3 : (off_sph + stack <= budget ? 1 : 0);
         if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries hold (record << 1 | slot) in 15 bits
         if (s->lds_level) {

@@ -72,13 +72,18 @@ constexpr uint32_t ORDERED_MAX_STACK = 32; // per-lane stack entries the kernel 
 enum OrderedSeqKind : uint32_t { OSEQ_TREE = 0, OSEQ_MEDIUM_SPHERE = 1, OSEQ_MEDIUM = 2 };
 struct alignas(16) OSeq {
     uint32_t kind;
-    uint32_t a;     // TREE: root record; media: medium index
-    uint32_t b;     // MEDIUM: root record of the boundary's tree
-    uint32_t _pad;
-    float box[6];   // (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi), f32 rounded outward: what the step can touch
-    uint32_t _pad2[2];
+    uint32_t a;      // TREE: root record; media: medium index
+    uint32_t b;      // MEDIUM: root record of the boundary's tree
+    uint32_t moving; // MEDIUM_SPHERE: the boundary sphere moves
+    float box[6];    // (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi), f32 rounded outward: what the step can touch
+    uint32_t _pad[2];
+    // everything a medium step needs, so that taking it touches no other table (the steps sit in the LDS)
+    double center[3], radius;  // MEDIUM_SPHERE: the boundary
+    double center_vec[3];
+    double neg_inv_density;    // media
 };
-static_assert(sizeof(OSeq) == 48, "OSeq must be 48 bytes");
+static_assert(sizeof(OSeq) == 112, "OSeq must be 112 bytes");
+constexpr uint32_t ORDERED_MAX_STEPS = 64; // steps of a world frame's sequence the kernel keeps in the LDS
 
 // 64 bytes
 struct alignas(64) Sphere {

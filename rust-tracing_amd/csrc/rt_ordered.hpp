@@ -80,13 +80,19 @@ class OrderedBuilder {
                 o.a = si.medium;
                 // the boundary sphere is in no leaf: it moves to the end of the (reordered) sphere table
                 const uint32_t old_index = cs_.media[si.medium].first_node;
-                b = sphere_bound(cs_.spheres[old_index]);
+                const Sphere &sp = cs_.spheres[old_index];
+                b = sphere_bound(sp);
+                for (int ax = 0; ax < 3; ++ax) { o.center[ax] = sp.center[ax]; o.center_vec[ax] = sp.center_vec[ax]; }
+                o.radius = sp.radius;
+                o.moving = sp.seq_moving & 1u;
+                o.neg_inv_density = cs_.media[si.medium].neg_inv_density;
                 cs_.media[si.medium].first_node = (uint32_t)new_spheres_.size();
                 new_spheres_.push_back(cs_.spheres[old_index]);
             } else {
                 if (frames_[si.frame].empty()) continue; // a boundary without geometry: the medium can never be hit
                 o.a = si.medium;
                 o.b = root_[si.frame];
+                o.neg_inv_density = cs_.media[si.medium].neg_inv_density;
                 need = std::max(need, need_[si.frame]);
                 b = bound_[si.frame];
             }
@@ -97,7 +103,7 @@ class OrderedBuilder {
             }
             seq.push_back(o);
         }
-        if (need > ORDERED_MAX_STACK) return false;
+        if (need > ORDERED_MAX_STACK || seq.size() > ORDERED_MAX_STEPS) return false;
         if (seq.empty()) { // nothing can be hit: one tree whose root has two empty children
             OSeq o{};
             o.kind = OSEQ_TREE;
