@@ -203,3 +203,27 @@ def media_scene(camera_from, order=0, nested=False):
     elif order == 2:
         items = items[1::2] + items[0::2]
     return s.finish(s.list(items))
+
+
+def nested_frames_scene(camera_from):
+    """Frames inside frames (RotateY inside Translate inside RotateY inside Translate ...), a sphere and a cube at every
+    level, plus a medium whose boundary is such a nest: hits are rebuilt through up to three enclosing frames."""
+    s = CustomScene(camera_from, spp=4, depth=8, background=(0.7, 0.8, 1.0))
+    mats = [s.lambertian(0.8, 0.3, 0.3), s.lambertian(0.3, 0.8, 0.3), s.metal(0.7, 0.7, 0.9, 0.1), s.dielectric(1.5), s.light(3, 3, 3)]
+
+    def cube(lo, hi, m):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
+        return [s.quad((x0, y0, z1), (dx, 0, 0), (0, dy, 0), m), s.quad((x1, y0, z1), (0, 0, -dz), (0, dy, 0), m),
+                s.quad((x1, y0, z0), (-dx, 0, 0), (0, dy, 0), m), s.quad((x0, y0, z0), (0, 0, dz), (0, dy, 0), m),
+                s.quad((x0, y1, z1), (dx, 0, 0), (0, 0, -dz), m), s.quad((x0, y0, z0), (dx, 0, 0), (0, 0, dz), m)]
+
+    inner = s.list(cube((-0.3, -0.3, -0.3), (0.3, 0.3, 0.3), mats[2]) + [s.sphere((0.0, 0.6, 0.0), 0.25, mats[3])])
+    level2 = s.list([s.translate(s.rotate_y(inner, 40.0), (0.8, 0.2, 0.0)), s.sphere((-0.5, 0.0, 0.3), 0.35, mats[0])] +
+                    cube((-0.2, -0.9, -0.2), (0.2, -0.5, 0.2), mats[1]))
+    level1 = s.list([s.rotate_y(s.translate(level2, (0.0, 0.5, -0.5)), -25.0), s.sphere((1.5, -0.5, 0.5), 0.4, mats[4])])
+    outer = s.translate(s.rotate_y(level1, 15.0), (-0.5, 0.0, 0.0))
+    smoke_nest = s.translate(s.rotate_y(s.list([s.translate(s.list(cube((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), mats[0])), (0.2, 0.0, 0.0))]), 35.0),
+                             (-2.0, -1.0, 0.5))
+    floor = s.quad((-4, -2, -4), (8, 0, 0), (0, 0, 8), mats[1])
+    return s.finish(s.list([floor, outer, s.medium(smoke_nest, 1.2, 0.1, 0.1, 0.1), s.sphere((2.2, -1.3, -0.5), 0.7, mats[2])]))

@@ -81,3 +81,11 @@ def test_medium_inside_a_frame_keeps_the_reference_walk(rt, oracle, gpu):
     want = oracle.render(scene, params)
     got = rt.DeviceScene(scene).render(params)
     assert (bits(got) == bits(want)).all()
+
+
+def test_frames_inside_frames(rt, oracle, gpu):
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.nested_frames_scene(cam)
+    st = rt.DeviceScene(scene).stats()
+    assert st["ordered"] == 1 and st["max_instance_depth"] >= 3
+    check(rt, oracle, scene, "nested frames")
