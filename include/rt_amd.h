@@ -235,7 +235,7 @@ typedef struct rt_render_params {
 typedef struct rt_counters {
     uint64_t samples;       /* camera paths traced                                          */
     uint64_t rays;          /* closest-hit queries issued by ray_color (src/renderer.rs:144) */
-    uint64_t node_visits;   /* bounding-box tests                                            */
+    uint64_t node_visits;   /* bounding-box tests; ordered walk: records visited (two boxes each) */
     uint64_t sphere_tests;
     uint64_t quad_tests;
     uint64_t medium_visits; /* ConstantMedium::hit entries (src/constant_medium.rs:34)       */
@@ -328,9 +328,10 @@ typedef struct rt_debug_node {
 int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity,
                             int64_t *out_count);
 
-/* Test / tuning hook: how scenes created from now on are walked.  ordered = 1 (default): scenes without a
- * ConstantMedium use the library's own trees, nearest child first; 0: every scene walks the reference's tree in the
- * reference's order.  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
+/* Test / tuning hook: how scenes created from now on are walked.  ordered = 1 (default): the library's own trees,
+ * nearest child first — with media, a sequence of trees and media in the reference's scan order (DESIGN.md "Ordered
+ * layout"; a medium inside a Translate / RotateY frame keeps the other walk); 0: every scene walks the reference's tree
+ * in the reference's order.  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
  * Affects speed only, never results. */
 int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
 

@@ -433,8 +433,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
                    HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
     constexpr bool HAS_OTHER = HAS_FRAMES || HAS_MEDIA;
-    // parked attenuations loaded per trip when a path ends: 4 where registers allow (the general kernels already spill)
-    constexpr uint32_t CHAIN = HAS_TEXTURES ? 1u : 4u;
+    // parked attenuations loaded per trip when a path ends: 4 where registers allow (the general kernels at 128 registers
+    // already spill; their 256-thread form has 168)
+    constexpr uint32_t CHAIN = (HAS_TEXTURES && LDS != 0) ? 1u : 4u;
     const double INF = __builtin_inf();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
