@@ -6,6 +6,14 @@ PNGs under screenshots/ (README.md:20-37).  Two of them show scenes with no buil
 camera settings, so a converged render of the same scene must reproduce them up to Monte-Carlo noise:
     cornell_box.png    600x600    src/main.rs:344-421
     cornell_smoke.png  600x600    src/main.rs:423-506
+A third shows a scene whose only build-time randomness is the Perlin tables of its marble texture, on a black
+background (no dependence on the sky), at the committed settings:
+    simple_light.png   600x337    src/main.rs:296-342
+Different tables move the marble's veins, not its average: the image mean is reproduced to a fraction of a per cent
+whatever the tables, and the means over a 3x3 grid to a few per cent — which pins Sphere::hit, the sphere and quad lights, the
+noise texture and the 16:9 camera, none of which the Cornell scenes contain.
+(earth.png, perlin.png and random_balls.png were rendered by an older revision with a gradient sky, like checker.png
+below; final_scene.png depends on the reference's earth-small.jpg and on 400 random box heights: none of them is used.)
 (checker.png shows the deterministic two_spheres scene too, but it was rendered by an older revision with a
 gradient sky: its sky pixels are (229,240,255), whereas the committed constant background (0.7,0.8,1.0),
 src/main.rs:163, encodes to (217,231,255).  Geometry agrees, colours cannot, so it is not used as a pin.)
@@ -30,6 +38,7 @@ GRID = 12
 SHOTS = {
     "cornell_box": {"file": "screenshots/cornell_box.png", "scene": 6, "source": "src/main.rs:344-421"},
     "cornell_smoke": {"file": "screenshots/cornell_smoke.png", "scene": 7, "source": "src/main.rs:423-506"},
+    "simple_light": {"file": "screenshots/simple_light.png", "scene": 5, "source": "src/main.rs:296-342"},
 }
 
 

@@ -1,6 +1,6 @@
 """Pins the oracle (and with it the host-side scene / BVH / camera / output code it is fed by) to the REFERENCE:
 the two deterministic scenes whose screenshots the reference publishes must come out the same, block for block,
-up to Monte-Carlo noise.  Fixture: tests/golden/reference_screenshot_stats.json (block means of the reference's
+up to Monte-Carlo noise; a third (simple_light) up to the position of its marble veins.  Fixture: tests/golden/reference_screenshot_stats.json (block means of the reference's
 PNGs, made by tests/golden/make_reference_stats.py).  This is the only reference-derived ground truth that exists:
 the reference has no tests, no golden vectors and an unseedable RNG."""
 import json
@@ -19,14 +19,18 @@ def block_means(a, grid):
     return np.array([[a[ys[r]:ys[r + 1], xs[q]:xs[q + 1]].reshape(-1, c).mean(axis=0) for q in range(grid)] for r in range(grid)])
 
 
-def compare(sums, spp, shot, mean_tol, rms_tol, max_tol):
+def compare(sums, spp, shot, mean_tol, rms_tol, max_tol, coarse=1):
+    """coarse: compare means over coarse x coarse groups of the fixture's blocks"""
     h, w = shot["height"], shot["width"]
     # the screenshot is color_to_rgb(mean): clamp to the same range before comparing in linear space
     lin = np.clip(sums.reshape(h, w, 3) / spp, 0.0, 0.999 ** 2.2)
     ref_mean = np.array(shot["mean_linear"])
     assert np.abs(lin.reshape(-1, 3).mean(axis=0) / ref_mean - 1).max() < mean_tol
-    rel = (block_means(lin, GOLD["grid"]) - np.array(shot["blocks_linear"])) / (np.array(shot["blocks_linear"]) + 0.01)
-    assert np.sqrt((rel ** 2).mean()) < rms_tol and np.abs(rel).max() < max_tol
+    g = GOLD["grid"] // coarse
+    group = lambda b: np.asarray(b).reshape(g, coarse, g, coarse, 3).mean(axis=(1, 3))
+    got, want = group(block_means(lin, GOLD["grid"])), group(shot["blocks_linear"])
+    rel = (got - want) / (want + 0.01)
+    assert np.sqrt((rel ** 2).mean()) < rms_tol and np.abs(rel).max() < max_tol, (np.sqrt((rel ** 2).mean()), np.abs(rel).max())
 
 
 @pytest.mark.parametrize("name,spp", [("cornell_box", 48), ("cornell_smoke", 32)])
@@ -37,6 +41,29 @@ def test_oracle_reproduces_the_reference_screenshot(rt, oracle, name, spp):
     sums = oracle.render(hs, rt.render_params(seed=7))
     # 48 / 32 spp leave ~3 % noise per 50x50 block; the global mean is far tighter
     compare(sums, spp, shot, mean_tol=0.015, rms_tol=0.04, max_tol=0.15)
+
+
+@pytest.mark.parametrize("scene_seed", [1, 2])
+def test_oracle_reproduces_the_simple_light_screenshot(rt, oracle, scene_seed):
+    """Spheres, a sphere light and a quad light, marble (Perlin) textures, black background: the only thing the build
+    cannot reproduce is the reference's random Perlin tables, which move the marble's veins but not its average — the
+    image mean agrees to a fraction of a per cent for any tables, 4x4-block groups to a few per cent."""
+    shot = GOLD["shots"]["simple_light"]
+    spp = 64
+    hs = rt.HostScene(shot["scene"], scene_seed=scene_seed, spp=spp)  # in-code camera: 600x337, depth 8 (src/main.rs:327-339)
+    assert (hs.width, hs.height) == (shot["width"], shot["height"]) and hs.camera.max_depth == 8
+    sums = oracle.render(hs, rt.render_params(seed=7))
+    compare(sums, spp, shot, mean_tol=0.015, rms_tol=0.05, max_tol=0.12, coarse=4)
+
+
+@pytest.mark.gpu
+def test_gpu_converged_simple_light_matches_the_reference_screenshot(rt, gpu):
+    shot = GOLD["shots"]["simple_light"]
+    spp = 2048
+    for scene_seed in (1, 2, 3):
+        hs = rt.HostScene(shot["scene"], scene_seed=scene_seed, spp=spp)
+        sums = rt.DeviceScene(hs).render(rt.render_params(seed=7))
+        compare(sums, spp, shot, mean_tol=0.01, rms_tol=0.04, max_tol=0.10, coarse=4)
 
 
 @pytest.mark.gpu
