@@ -84,6 +84,7 @@ struct KParams {
     // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
     const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
     const OSeq *oseq;               // the world frame's sequence of trees and media (rt_layout.h)
+    float box_extent;               // the largest |coordinate| of any box of the ordered layout (box_pair_f32's B)
     uint32_t n_oseq;
     uint32_t o_root;
     uint32_t lds_stack_off;
@@ -345,25 +346,33 @@ RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, f
     const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
     return !r.degenerate && gap > tol; // a NaN compares false: pass
 }
-// The ordered walk tests the two boxes of a record at once, in a form with half the instructions: per axis the plane
-// the ray meets first is known from the sign of 1/d (load_opair reads the table laid out for that sign), and each slab
+// The ordered walk tests the two boxes of a record at once, in a form with a third of the instructions: per axis the plane
+// the ray meets first is known from the sign of 1/d (load_opair reads the table laid out for that sign), each slab
 // distance is ONE fused multiply-add
 //     t = b * (1/d) - (o * (1/d) +- E)          (explicit fma: this f32 filter is not part of the f64 arithmetic contract)
-// with the product o * (1/d) and the outward shift E folded into two per-ray constants (`n` for entering planes, `f` for
-// leaving ones).  Error budget, relative to |o / d| on that axis: o -> f32 2^-24, the product 2^-24, adding E 2^-24 —
-// under E = 2^-21 |o / d|; relative to t itself: 1/d 2^-22 (conversion + v_rcp_f32), the fma's rounding 2^-24, tmin / tmax
-// 2^-24 — under the 2^-20 (|enter| + |leave|) the test tolerates.  So, as for box_miss_f32, it passes whenever the exact
-// test does.  Both boxes of the pair go through packed (2 x f32) fmas.
+// with the product o * (1/d) and an outward shift E folded into two per-ray constants per axis (`n` for entering planes,
+// `f` for leaving ones), and the verdict is a plain comparison enter > leave.  E is an ABSOLUTE bound on everything that
+// rounding can do to t on that axis, for any plane of the scene: with |b| <= B (the largest coordinate of any box, from the
+// scene compiler) and i = 1/d,
+//     |b i' - b i| <= 2^-22 B |i|           (1/d: conversion of d to f32 + v_rcp_f32)
+//     |p - o i|    <= 1.6 * 2^-22 |o i|      (o -> f32, the same 1/d, the product's rounding)
+//     rounding of p +- E and of the fma: <= 2^-23 (B |i| + |o i|)
+// together under 2^-21 (B |i| + |o i|); E = 2^-20 (B |i| + |o i|) leaves a factor two.  Entering distances are therefore
+// never over-, leaving distances never under-estimated; the interval ends are rounded outward when they are converted
+// (tmin32 down, tmax32 up).  So the test passes whenever the exact one does (tests: rt_debug_box_tests).  In world
+// units E is 2^-20 (B + |o|): random-spheres 2 mm (B = 2000, the ground sphere), Cornell 0.5 mm.
 struct RayPair32 {
     float ix, iy, iz, nx, ny, nz, fx, fy, fz;
     uint32_t offx, offy, offz; // byte offsets of the tables this ray reads (load_opair): X+ or X-, Y+ or Y-, Z+ or Z-
     bool degenerate;
 };
-RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes) {
+RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes, float extent) {
     RayPair32 r;
     r.ix = __builtin_amdgcn_rcpf((float)d.x); r.iy = __builtin_amdgcn_rcpf((float)d.y); r.iz = __builtin_amdgcn_rcpf((float)d.z);
     const float px = (float)o.x * r.ix, py = (float)o.y * r.iy, pz = (float)o.z * r.iz;
-    const float ex = __builtin_fabsf(px) * 0x1p-21f, ey = __builtin_fabsf(py) * 0x1p-21f, ez = __builtin_fabsf(pz) * 0x1p-21f;
+    const float ex = (extent * __builtin_fabsf(r.ix) + __builtin_fabsf(px)) * 0x1p-20f;
+    const float ey = (extent * __builtin_fabsf(r.iy) + __builtin_fabsf(py)) * 0x1p-20f;
+    const float ez = (extent * __builtin_fabsf(r.iz) + __builtin_fabsf(pz)) * 0x1p-20f;
     r.nx = px + ex; r.ny = py + ey; r.nz = pz + ez;
     r.fx = px - ex; r.fy = py - ey; r.fz = pz - ez;
     r.offx = (r.ix < 0.0f ? 1u : 0u) * table_bytes;
@@ -374,19 +383,26 @@ RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes) {
     return r;
 }
 // enter0 / enter1: where the ray enters each box (for choosing which child to walk first: any choice is correct, the
-// nearer one prunes more)
+// nearer one prunes more).  tmin32 / tmax32: the interval, rounded outward.
 RT_DEV void box_pair_f32(const OPair &b, const RayPair32 &r, float tmin32, float tmax32, bool &miss0, bool &miss1, float &enter0,
                          float &enter1) {
     const f32x2 ix = {r.ix, r.ix}, iy = {r.iy, r.iy}, iz = {r.iz, r.iz};
     const f32x2 tnx = __builtin_elementwise_fma(b.nx, ix, f32x2{-r.nx, -r.nx}), tfx = __builtin_elementwise_fma(b.fx, ix, f32x2{-r.fx, -r.fx});
     const f32x2 tny = __builtin_elementwise_fma(b.ny, iy, f32x2{-r.ny, -r.ny}), tfy = __builtin_elementwise_fma(b.fy, iy, f32x2{-r.fy, -r.fy});
     const f32x2 tnz = __builtin_elementwise_fma(b.nz, iz, f32x2{-r.nz, -r.nz}), tfz = __builtin_elementwise_fma(b.fz, iz, f32x2{-r.fz, -r.fz});
-    const float en0 = __builtin_fmaxf(__builtin_fmaxf(tnx.x, tny.x), __builtin_fmaxf(tnz.x, tmin32));
-    const float en1 = __builtin_fmaxf(__builtin_fmaxf(tnx.y, tny.y), __builtin_fmaxf(tnz.y, tmin32));
-    const float le0 = __builtin_fminf(__builtin_fminf(tfx.x, tfy.x), __builtin_fminf(tfz.x, tmax32));
-    const float le1 = __builtin_fminf(__builtin_fminf(tfx.y, tfy.y), __builtin_fminf(tfz.y, tmax32));
-    miss0 = !r.degenerate && (en0 - le0) > (__builtin_fabsf(en0) + __builtin_fabsf(le0)) * 0x1p-20f; // a NaN compares false: pass
-    miss1 = !r.degenerate && (en1 - le1) > (__builtin_fabsf(en1) + __builtin_fabsf(le1)) * 0x1p-20f;
+    // (v_max3 / v_min3 spelled out: through fmaxf the compiler first "quiets" each operand it cannot prove is no signalling
+    // NaN — one extra instruction per operand, five per visit; the instructions themselves return the non-NaN operand)
+    float en0, en1, le0, le1;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(en0) : "v"(tnx.x), "v"(tny.x), "v"(tnz.x));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(en1) : "v"(tnx.y), "v"(tny.y), "v"(tnz.y));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(le0) : "v"(tfx.x), "v"(tfy.x), "v"(tfz.x));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(le1) : "v"(tfx.y), "v"(tfy.y), "v"(tfz.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(en0) : "v"(en0), "v"(tmin32));
+    asm("v_max_f32 %0, %1, %2" : "=v"(en1) : "v"(en1), "v"(tmin32));
+    asm("v_min_f32 %0, %1, %2" : "=v"(le0) : "v"(le0), "v"(tmax32));
+    asm("v_min_f32 %0, %1, %2" : "=v"(le1) : "v"(le1), "v"(tmax32));
+    miss0 = !r.degenerate && en0 > le0; // a NaN compares false: pass
+    miss1 = !r.degenerate && en1 > le1;
     enter0 = en0;
     enter1 = en1;
 }
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // f32 copies for the conservative box test: origin, 1/d, and the bound E on what rounding the origin to f32
     // can move a slab distance (see the box stage); `degenerate`: some 1/d or E is not finite -> enter every box
     std::conditional_t<ORDERED, RayPair32, Ray32> r32;
-    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b); else r32 = make_ray32(o, d);
+    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b, P.box_extent); else r32 = make_ray32(o, d);
     float tmin32 = 0, tmax32 = 0;
     uint32_t job = 0;
     int32_t depth = 0;
@@ -483,46 +499,46 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     uint32_t mode = 0; // ConstantMedium: 0 outside, 1 first boundary query, 2 second; bit 8: boundary was hit
     uint32_t stage = ST_NEWJOB + TERM_STORED;
     // ---- ordered walk: a stack of children set aside (one entry per level at most), in the LDS, [level][thread] ----
-    // entry < S_TOP: an inner record to visit; S_TOP | (record << 1 | slot): a leaf child whose box is tested again when
-    // its turn comes (the interval has usually shrunk by then); S_EXIT: leave the current frame
+    // An entry is what `node` shall hold when the entry's turn comes: an inner record's index, or — for a LEAF child — its
+    // parent's index with the "skip the other child" bit, so that the leaf's box is tested again, against the interval as
+    // it has shrunk by then, before its primitive is (a sphere test costs 2-3 box rounds); S_EXIT: leave the current frame.
     using StackT = std::conditional_t<LDS != 0, uint16_t, uint32_t>;
-    constexpr uint32_t S_TOP = LDS != 0 ? 0x8000u : 0x80000000u, S_EXIT = LDS != 0 ? 0xffffu : 0xffffffffu;
-    constexpr uint32_t SKIP_CHILD0 = 0x40000000u, SKIP_CHILD1 = 0x80000000u, NODE_INDEX = 0x3fffffffu, NODE_FRAME_EXIT = 0xffffffffu,
-                       NODE_SEQ_NEXT = 0xfffffffeu; // ST_OTHER: leave the current frame / take the next step of the world's sequence
+    constexpr uint32_t S_EXIT = LDS != 0 ? 0xffffu : 0xffffffffu;
+    constexpr uint32_t SKIP_CHILD0 = LDS != 0 ? 0x4000u : 0x40000000u, SKIP_CHILD1 = LDS != 0 ? 0x8000u : 0x80000000u,
+                       NODE_INDEX = SKIP_CHILD0 - 1u;
+    constexpr uint32_t NODE_FRAME_EXIT = 0xffffffffu, NODE_SEQ_NEXT = 0xfffffffeu; // ST_OTHER: leave the current frame / take the next step of the world's sequence
     StackT *const stack = reinterpret_cast<StackT *>(lds_raw + P.lds_stack_off) + threadIdx.x;
     uint32_t sp = 0;
     uint32_t seq_pc = 0; // (scenes with media) the next step of the world frame's sequence
     const uint32_t first_node = ORDERED ? P.o_root : 0u;
     // what a lane does next in an ordered walk: go to `ref` if it has one, else take the last child set aside
+    // (written as selects of VALUES: when the branches assign different variables the optimiser turns them into one store
+    // through a selected address, and the variables end up in scratch memory — in the hottest loop of the kernel)
     auto o_next = [&](bool have, uint32_t ref) {
-        if (!have) {
-            if (sp == 0) { // this tree is done
-                if constexpr (HAS_MEDIA) { // ... the world's sequence may go on; a boundary query reports to its medium
-                    if (seq_pc < P.n_oseq || (mode & 3u) != 0) { node = NODE_SEQ_NEXT; stage = ST_OTHER; return; }
-                }
-                stage = ST_SHADE;
-                return;
-            }
+        uint32_t new_stage, new_node = node, new_cur = prim_cur, new_end = prim_end;
+        if (have) {
+            // OrderedKind INNER / SPHERES / QUADS / INSTANCE = 0 / 1 / 2 / 3 = Stage ST_BOX / ST_SPHERE / ST_QUAD / ST_OTHER
+            const uint32_t kind = ref >> OREF_KIND_SHIFT, index = ref & OREF_INDEX_MASK;
+            const bool leaf = kind == OK_SPHERES || kind == OK_QUADS;
+            new_stage = kind;
+            new_node = leaf ? node : index;
+            new_cur = leaf ? index : prim_cur;
+            new_end = leaf ? index + ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u : prim_end;
+        } else if (sp != 0) { // the last child set aside
             sp--;
             const uint32_t e = stack[sp * THREADS];
-            if (e == S_EXIT) { node = NODE_FRAME_EXIT; stage = ST_OTHER; return; }
-            if (e & S_TOP) {
-                const uint32_t ps = e & (S_TOP - 1u);
-                node = (ps >> 1) | ((ps & 1u) ? SKIP_CHILD0 : SKIP_CHILD1);
-                stage = ST_BOX;
-                return;
+            const bool leave_frame = HAS_FRAMES && e == S_EXIT;
+            new_node = leave_frame ? NODE_FRAME_EXIT : e;
+            new_stage = leave_frame ? (uint32_t)ST_OTHER : (uint32_t)ST_BOX;
+        } else { // this tree is done
+            new_stage = ST_SHADE;
+            if constexpr (HAS_MEDIA) { // ... the world's sequence may go on; a boundary query reports to its medium
+                const bool more = seq_pc < P.n_oseq || (mode & 3u) != 0;
+                new_node = more ? NODE_SEQ_NEXT : node;
+                new_stage = more ? (uint32_t)ST_OTHER : (uint32_t)ST_SHADE;
             }
-            ref = e;
         }
-        // OrderedKind INNER / SPHERES / QUADS / INSTANCE = 0 / 1 / 2 / 3 = Stage ST_BOX / ST_SPHERE / ST_QUAD / ST_OTHER
-        const uint32_t kind = ref >> OREF_KIND_SHIFT;
-        stage = kind;
-        if (kind == OK_SPHERES || kind == OK_QUADS) {
-            prim_cur = ref & OREF_INDEX_MASK;
-            prim_end = prim_cur + ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u;
-        } else {
-            node = ref & OREF_INDEX_MASK;
-        }
+        stage = new_stage; node = new_node; prim_cur = new_cur; prim_end = new_end;
     };
     // ties (ordered walk): two primitives hit at exactly the same t.  The reference scans in a fixed order and keeps the
     // first unless a later one passes its interval test: Sphere::hit wants t < closest (Interval::surrounds,
@@ -550,12 +566,13 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     const int32_t w = P.cam.image_width, h = P.cam.image_height;
 
     auto refresh_ray32 = [&]() {
-        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b);
+        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b, P.box_extent);
         else r32 = make_ray32(o, d);
     };
+    // (the ordered walk's test takes the interval rounded outward; the threaded one has the slack for either rounding)
     auto refresh_interval32 = [&]() {
-        tmin32 = (float)cur_tmin;
-        tmax32 = (float)cur_tmax;
+        tmin32 = ORDERED ? __double2float_rd(cur_tmin) : (float)cur_tmin;
+        tmax32 = ORDERED ? __double2float_ru(cur_tmax) : (float)cur_tmax;
     };
 
     // ---- ConstantMedium::hit (src/constant_medium.rs:33-71), shared by both walks ----
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 seq_pc++;
                 float enter;
                 bool miss0, miss1;
-                box_pair_f32(opair_of_box(rec->box, r32), r32, (float)cur_tmin, (float)cur_tmax, miss0, miss1, enter, enter);
+                box_pair_f32(opair_of_box(rec->box, r32), r32, __double2float_rd(cur_tmin), __double2float_ru(cur_tmax), miss0, miss1, enter, enter);
                 if (miss0) continue;
                 if (rec->kind == OSEQ_TREE) {
                     node = rec->a; sp = 0; stage = ST_BOX;
@@ -744,13 +761,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         bool m0, m1;
                         box_pair_f32(nd, r32, tmin32, tmax32, m0, m1, e0, e1);
                         bool h0 = !m0, h1 = !m1;
-                        h0 = h0 && !(node & SKIP_CHILD0) && (nd.c0 >> OREF_KIND_SHIFT) != OK_EMPTY;
-                        h1 = h1 && !(node & SKIP_CHILD1) && (nd.c1 >> OREF_KIND_SHIFT) != OK_EMPTY;
+                        h0 = h0 & ((node & SKIP_CHILD0) == 0u) & (nd.c0 < (OK_EMPTY << OREF_KIND_SHIFT));
+                        h1 = h1 & ((node & SKIP_CHILD1) == 0u) & (nd.c1 < (OK_EMPTY << OREF_KIND_SHIFT));
                         const bool one_first = h1 && (!h0 || e1 < e0);
                         if (h0 && h1) {
-                            const uint32_t far_slot = one_first ? 0u : 1u;
                             const uint32_t far_ref = one_first ? nd.c0 : nd.c1;
-                            const uint32_t entry = (far_ref >> OREF_KIND_SHIFT) == OK_INNER ? far_ref : (S_TOP | (nid << 1) | far_slot);
+                            const uint32_t entry = far_ref < (1u << OREF_KIND_SHIFT) ? far_ref : (nid | (one_first ? SKIP_CHILD1 : SKIP_CHILD0));
                             stack[sp * THREADS] = (StackT)entry;
                             sp++;
                         }
@@ -811,7 +827,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                     if (ok) {
                         cur_tmax = root;
-                        tmax32 = (float)root;
+                        tmax32 = ORDERED ? __double2float_ru(root) : (float)root;
                         if (!HAS_MEDIA || (mode & 3u) == 0) { best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
                         else mode |= 0x100u;
                     }
@@ -842,7 +858,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const double beta = dot(qw, cross(ld3(qd->u), php));
                     if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
                     cur_tmax = t;
-                    tmax32 = (float)t;
+                    tmax32 = ORDERED ? __double2float_ru(t) : (float)t;
                     if (!HAS_MEDIA || (mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
                     else mode |= 0x100u;
                 }
@@ -1269,8 +1285,10 @@ __global__ void debug_box_kernel(int64_t n, const double *__restrict__ rays, con
     const float bb[6] = {lo32[0], hi32[0], lo32[1], hi32[1], lo32[2], hi32[2]};
     bool m0, m1;
     float e0, e1;
-    const RayPair32 rp = make_ray_pair32(o, d, 0u);
-    box_pair_f32(opair_of_box(bb, rp), rp, (float)tmin, (float)tmax, m0, m1, e0, e1);
+    float extent = 0.0f; // the scene compiler's B is at least the largest coordinate of this box
+    for (int k = 0; k < 6; ++k) extent = __builtin_fmaxf(extent, __builtin_fabsf(bb[k]));
+    const RayPair32 rp = make_ray_pair32(o, d, 0u, extent);
+    box_pair_f32(opair_of_box(bb, rp), rp, __double2float_rd(tmin), __double2float_ru(tmax), m0, m1, e0, e1);
     f32_hit[idx] = (uint8_t)((single ? 1 : 0) | (m0 ? 0 : 2) | (m1 ? 0 : 4)); // bit 0: box_miss_f32, bits 1-2: box_pair_f32
 }
 
@@ -1419,6 +1437,7 @@ struct rt_scene {
     DeviceArray<uint4> oimage;                   // ordered layout: the tables of load_opair (global copy)
     DeviceArray<OSeq> oseq;                      // ... and the world frame's sequence
     uint32_t n_oseq = 0;
+    float box_extent = 0.0f;                     // largest |coordinate| of any box of the ordered layout
     uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
     rt_scene_stats stats{};
     std::mutex mu;
@@ -1622,6 +1641,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
+    K.box_extent = scene->box_extent;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
@@ -1727,6 +1747,13 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
     // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
     s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
     s->n_oseq = (uint32_t)cs.oseq.size();
+    for (const ONode &nd : cs.onodes)
+        for (int k = 0; k < 6; ++k) {
+            if ((nd.c[0] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b0[k]));
+            if ((nd.c[1] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b1[k]));
+        }
+    for (const OSeq &st : cs.oseq)
+        for (int k = 0; k < 6; ++k) s->box_extent = std::fmax(s->box_extent, std::fabs(st.box[k]));
     s->o_stack = cs.ordered_stack;
     // Node tables (load_node / load_opair): threaded records as two 16-byte halves, ordered records as six 16-byte plane
     // tables and an 8-byte reference table.  LDS image = node tables | spheres | quads; every LDS level copies a prefix.
@@ -1766,7 +1793,7 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
         // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
         const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
         s->lds_level = total + stack <= budget ? 3 : (off_sph + stack <= budget ? 1 : 0);
-        if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries hold (record << 1 | slot) in 15 bits
+        if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits
         if (s->lds_level) {
             const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
             std::vector<uint4> img(used / 16);
