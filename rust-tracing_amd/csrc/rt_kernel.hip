@@ -361,35 +361,53 @@ RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, f
 // never over-, leaving distances never under-estimated; the interval ends are rounded outward when they are converted
 // (tmin32 down, tmax32 up).  So the test passes whenever the exact one does (tests: rt_debug_box_tests).  In world
 // units E is 2^-20 (B + |o|): random-spheres 2 mm (B = 2000, the ground sphere), Cornell 0.5 mm.
+// The per-ray constants are kept as five register pairs, already negated where the fma subtracts, and each packed fma
+// picks the half it needs for BOTH boxes through op_sel — so nothing has to be duplicated or negated per visit.
 struct RayPair32 {
-    float ix, iy, iz, nx, ny, nz, fx, fy, fz;
+    f32x2 ixy;  // (1/d.x, 1/d.y)
+    f32x2 izs;  // (1/d.z, sign bits as float bits: unused half)
+    f32x2 nxy;  // -(o/d + E) on x, y: entering planes
+    f32x2 fxy;  // -(o/d - E) on x, y: leaving planes
+    f32x2 nfz;  // the same two constants on z
     uint32_t offx, offy, offz; // byte offsets of the tables this ray reads (load_opair): X+ or X-, Y+ or Y-, Z+ or Z-
     bool degenerate;
 };
 RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes, float extent) {
     RayPair32 r;
-    r.ix = __builtin_amdgcn_rcpf((float)d.x); r.iy = __builtin_amdgcn_rcpf((float)d.y); r.iz = __builtin_amdgcn_rcpf((float)d.z);
-    const float px = (float)o.x * r.ix, py = (float)o.y * r.iy, pz = (float)o.z * r.iz;
-    const float ex = (extent * __builtin_fabsf(r.ix) + __builtin_fabsf(px)) * 0x1p-20f;
-    const float ey = (extent * __builtin_fabsf(r.iy) + __builtin_fabsf(py)) * 0x1p-20f;
-    const float ez = (extent * __builtin_fabsf(r.iz) + __builtin_fabsf(pz)) * 0x1p-20f;
-    r.nx = px + ex; r.ny = py + ey; r.nz = pz + ez;
-    r.fx = px - ex; r.fy = py - ey; r.fz = pz - ez;
-    r.offx = (r.ix < 0.0f ? 1u : 0u) * table_bytes;
-    r.offy = (r.iy < 0.0f ? 3u : 2u) * table_bytes;
-    r.offz = (r.iz < 0.0f ? 5u : 4u) * table_bytes;
-    const float fsum = (ex + ey + ez) + (__builtin_fabsf(r.ix) + __builtin_fabsf(r.iy) + __builtin_fabsf(r.iz));
+    const float ix = __builtin_amdgcn_rcpf((float)d.x), iy = __builtin_amdgcn_rcpf((float)d.y), iz = __builtin_amdgcn_rcpf((float)d.z);
+    const float px = (float)o.x * ix, py = (float)o.y * iy, pz = (float)o.z * iz;
+    const float ex = (extent * __builtin_fabsf(ix) + __builtin_fabsf(px)) * 0x1p-20f;
+    const float ey = (extent * __builtin_fabsf(iy) + __builtin_fabsf(py)) * 0x1p-20f;
+    const float ez = (extent * __builtin_fabsf(iz) + __builtin_fabsf(pz)) * 0x1p-20f;
+    r.ixy = f32x2{ix, iy};
+    r.izs = f32x2{iz, 0.0f};
+    r.nxy = f32x2{-(px + ex), -(py + ey)};
+    r.fxy = f32x2{-(px - ex), -(py - ey)};
+    r.nfz = f32x2{-(pz + ez), -(pz - ez)};
+    r.offx = (ix < 0.0f ? 1u : 0u) * table_bytes;
+    r.offy = (iy < 0.0f ? 3u : 2u) * table_bytes;
+    r.offz = (iz < 0.0f ? 5u : 4u) * table_bytes;
+    const float fsum = (ex + ey + ez) + (__builtin_fabsf(ix) + __builtin_fabsf(iy) + __builtin_fabsf(iz));
     r.degenerate = !(fsum < __builtin_inff()); // an inf or a NaN anywhere: every box is entered
     return r;
 }
+// planes * (the chosen half of inv, for both boxes) + (the chosen half of off, for both boxes)
+#define RT_PK_FMA_SEL(out, planes, inv, off, SEL)                                                             \
+    asm("v_pk_fma_f32 %0, %1, %2, %3 " SEL : "=v"(out) : "v"(planes), "v"(inv), "v"(off))
+#define RT_SEL_LO_LO "op_sel:[0,0,0] op_sel_hi:[1,0,0]" /* inv.lo, off.lo */
+#define RT_SEL_HI_HI "op_sel:[0,1,1] op_sel_hi:[1,1,1]" /* inv.hi, off.hi */
+#define RT_SEL_LO_HI "op_sel:[0,0,1] op_sel_hi:[1,0,1]" /* inv.lo, off.hi */
 // enter0 / enter1: where the ray enters each box (for choosing which child to walk first: any choice is correct, the
 // nearer one prunes more).  tmin32 / tmax32: the interval, rounded outward.
 RT_DEV void box_pair_f32(const OPair &b, const RayPair32 &r, float tmin32, float tmax32, bool &miss0, bool &miss1, float &enter0,
                          float &enter1) {
-    const f32x2 ix = {r.ix, r.ix}, iy = {r.iy, r.iy}, iz = {r.iz, r.iz};
-    const f32x2 tnx = __builtin_elementwise_fma(b.nx, ix, f32x2{-r.nx, -r.nx}), tfx = __builtin_elementwise_fma(b.fx, ix, f32x2{-r.fx, -r.fx});
-    const f32x2 tny = __builtin_elementwise_fma(b.ny, iy, f32x2{-r.ny, -r.ny}), tfy = __builtin_elementwise_fma(b.fy, iy, f32x2{-r.fy, -r.fy});
-    const f32x2 tnz = __builtin_elementwise_fma(b.nz, iz, f32x2{-r.nz, -r.nz}), tfz = __builtin_elementwise_fma(b.fz, iz, f32x2{-r.fz, -r.fz});
+    f32x2 tnx, tny, tnz, tfx, tfy, tfz;
+    RT_PK_FMA_SEL(tnx, b.nx, r.ixy, r.nxy, RT_SEL_LO_LO);
+    RT_PK_FMA_SEL(tny, b.ny, r.ixy, r.nxy, RT_SEL_HI_HI);
+    RT_PK_FMA_SEL(tnz, b.nz, r.izs, r.nfz, RT_SEL_LO_LO);
+    RT_PK_FMA_SEL(tfx, b.fx, r.ixy, r.fxy, RT_SEL_LO_LO);
+    RT_PK_FMA_SEL(tfy, b.fy, r.ixy, r.fxy, RT_SEL_HI_HI);
+    RT_PK_FMA_SEL(tfz, b.fz, r.izs, r.nfz, RT_SEL_LO_HI);
     // (v_max3 / v_min3 spelled out: through fmaxf the compiler first "quiets" each operand it cannot prove is no signalling
     // NaN — one extra instruction per operand, five per visit; the instructions themselves return the non-NaN operand)
     float en0, en1, le0, le1;
@@ -409,7 +427,7 @@ RT_DEV void box_pair_f32(const OPair &b, const RayPair32 &r, float tmin32, float
 // one box given as (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi) in both slots of a pair, as the "+" / "-" tables would hold it
 RT_DEV OPair opair_of_box(const float b[6], const RayPair32 &r) {
     OPair p;
-    const bool sx = r.ix < 0.0f, sy = r.iy < 0.0f, sz = r.iz < 0.0f;
+    const bool sx = r.ixy.x < 0.0f, sy = r.ixy.y < 0.0f, sz = r.izs.x < 0.0f;
     p.nx = f32x2{sx ? b[1] : b[0], sx ? b[1] : b[0]}; p.fx = f32x2{sx ? b[0] : b[1], sx ? b[0] : b[1]};
     p.ny = f32x2{sy ? b[3] : b[2], sy ? b[3] : b[2]}; p.fy = f32x2{sy ? b[2] : b[3], sy ? b[2] : b[3]};
     p.nz = f32x2{sz ? b[5] : b[4], sz ? b[5] : b[4]}; p.fz = f32x2{sz ? b[4] : b[5], sz ? b[4] : b[5]};
