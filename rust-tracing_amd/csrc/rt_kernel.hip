@@ -70,6 +70,7 @@ struct KParams {
     uint32_t n_samples;             // samples per pixel in this launch
     uint32_t n_jobs;                // n_local_tiles * n_samples * 64
     uint32_t jobs_per_grab;
+    double inv_n_samples, inv_tiles_x; // 1 / n_samples, 1 / tiles_x (job decode)
     int32_t max_depth, accumulate;
     int32_t shard_index, shard_count, out_layout;
     int32_t tiles_x;
@@ -1145,10 +1146,13 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         // job -> (local tile, sample, pixel): ((lt * S + s_rel) * 64 + p)
                         const uint32_t p64 = job & 63u;
                         const uint32_t row = job >> 6;
-                        const uint32_t lt = row / P.n_samples, s_rel = row - lt * P.n_samples;
+                        // n / d for n < 2^27 as trunc((n + 0.5) * (1 / d)) in f64: (n + 0.5) / d is at least 0.5 / d away from an
+                        // integer, far more than the 2^-52 relative error of the product — exact, and 4 instructions, not 25
+                        const uint32_t lt = (uint32_t)(((double)row + 0.5) * P.inv_n_samples), s_rel = row - lt * P.n_samples;
                         const uint32_t k = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
-                        const int32_t i = (int32_t)(k % (uint32_t)P.tiles_x) * RT_TILE_W + (int32_t)(p64 & 7u);
-                        const int32_t j = (int32_t)(k / (uint32_t)P.tiles_x) * RT_TILE_H + (int32_t)(p64 >> 3);
+                        const uint32_t tile_row = (uint32_t)(((double)k + 0.5) * P.inv_tiles_x), tile_col = k - tile_row * (uint32_t)P.tiles_x;
+                        const int32_t i = (int32_t)tile_col * RT_TILE_W + (int32_t)(p64 & 7u);
+                        const int32_t j = (int32_t)tile_row * RT_TILE_H + (int32_t)(p64 >> 3);
                         if (i < w && j < h) {
                             const uint32_t pixel = (uint32_t)j * (uint32_t)w + (uint32_t)i; // screen_pos (src/renderer.rs:32-33)
                             rng.start(P.seed_mixed, pixel, (uint32_t)P.sample_begin + s_rel);
@@ -1654,6 +1658,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.max_depth = p.max_depth;
     K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
     K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
+    K.inv_tiles_x = 1.0 / (double)K.tiles_x;
     K.n_local_tiles = (uint32_t)n_local;
     K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
@@ -1675,6 +1680,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         K.sample_begin = (int32_t)sb;
         K.n_samples = (uint32_t)ns;
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
+        K.inv_n_samples = 1.0 / (double)ns;
         {
             // ~32 grabs per wave or more, rounded down to a multiple of 64 within [MIN, MAX]
             const int64_t waves = grid * waves_per_block;
