@@ -575,7 +575,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     };
 
     double *att = P.att_stack + (size_t)gtid * 3u;
-    const size_t att_stride = (size_t)P.n_threads * 3u;
+    const uint32_t att_stride = P.n_threads * 3u; // (32-bit element indices: launch_render checks the stack has < 2^32 doubles)
 
     // wave-uniform: the job range this wave currently owns
     uint32_t job_next = 0, job_end = 0;
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 }
                 if (!path_done) {
                     if (!unit_attenuation) {
-                        double *slot = att + (size_t)n_att * att_stride;
+                        double *slot = att + n_att * att_stride;
                         slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
                         n_att++;
                     }
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
                         // a light: the emitted colour is parked like one more attenuation and the path ends on Color::ONE
                         // (emitted * 1.0 is emitted, bit for bit), so the chain of products is written once, in ST_NEWJOB
-                        double *slot = att + (size_t)n_att * att_stride;
+                        double *slot = att + n_att * att_stride;
                         slot[0] = result.x; slot[1] = result.y; slot[2] = result.z;
                         n_att++;
                         stage = ST_NEWJOB + TERM_ONE;
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     #pragma unroll
                             for (uint32_t j = 0; j < CHAIN; ++j) {
                                 const uint32_t level = n_att > j ? n_att - 1u - j : 0u;
-                                const double *slot = att + (size_t)level * att_stride;
+                                const double *slot = att + level * att_stride;
                                 parked[j] = v3(slot[0], slot[1], slot[2]);
                             }
                     #pragma unroll
@@ -1614,6 +1614,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         std::lock_guard<std::mutex> lock(scene->mu);
         Workspace &w = scene->workspaces[stream];
         const size_t need_att = ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double); // + a light's emitted colour
+        if (need_att / sizeof(double) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the attenuation stack's 32-bit indices");
         const size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
         if (w.att_bytes < need_att || w.sample_bytes < need_samples) HIP_TRY(hipStreamSynchronize(stream));
         if (w.att_bytes < need_att) {
