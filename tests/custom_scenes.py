@@ -227,3 +227,69 @@ def nested_frames_scene(camera_from):
                              (-2.0, -1.0, 0.5))
     floor = s.quad((-4, -2, -4), (8, 0, 0), (0, 0, 8), mats[1])
     return s.finish(s.list([floor, outer, s.medium(smoke_nest, 1.2, 0.1, 0.1, 0.1), s.sphere((2.2, -1.3, -0.5), 0.7, mats[2])]))
+
+
+def random_scene(camera_from, seed):
+    """A random object graph for fuzzing the two walks against the oracle: spheres, quads and cubes, alone or grouped
+    in (nested) Translate / RotateY frames, media bounded by spheres, cubes and framed cubes at random places of the
+    world list, some objects duplicated exactly (ties), random materials."""
+    import random
+    rnd = random.Random(seed)
+    s = CustomScene(camera_from, spp=2, depth=6, background=(0.7, 0.8, 1.0) if rnd.random() < 0.7 else (0.0, 0.0, 0.0))
+    mats = [s.lambertian(rnd.random(), rnd.random(), rnd.random()) for _ in range(4)]
+    mats += [s.metal(rnd.random(), rnd.random(), rnd.random(), rnd.choice([0.0, 0.3, 1.5])), s.dielectric(rnd.choice([1.5, 1.0 / 1.5, 2.4])),
+             s.light(rnd.uniform(1, 8), rnd.uniform(1, 8), rnd.uniform(1, 8))]
+
+    def pos(scale=2.5):
+        return (rnd.uniform(-scale, scale), rnd.uniform(-scale, scale), rnd.uniform(-scale, scale))
+
+    def cube(m):
+        x0, y0, z0 = pos(2.0)
+        dx, dy, dz = rnd.uniform(0.2, 1.2), rnd.uniform(0.2, 1.2), rnd.uniform(0.2, 1.2)
+        x1, y1, z1 = x0 + dx, y0 + dy, z0 + dz
+        return [s.quad((x0, y0, z1), (dx, 0, 0), (0, dy, 0), m), s.quad((x1, y0, z1), (0, 0, -dz), (0, dy, 0), m),
+                s.quad((x1, y0, z0), (-dx, 0, 0), (0, dy, 0), m), s.quad((x0, y0, z0), (0, 0, dz), (0, dy, 0), m),
+                s.quad((x0, y1, z1), (dx, 0, 0), (0, 0, -dz), m), s.quad((x0, y0, z0), (dx, 0, 0), (0, 0, dz), m)]
+
+    def solid(depth):
+        kind = rnd.choice(["sphere", "sphere", "quad", "cube", "group"] if depth < 2 else ["sphere", "quad", "cube"])
+        m = rnd.choice(mats)
+        if kind == "sphere":
+            return [s.sphere(pos(), rnd.uniform(0.15, 0.9), m)]
+        if kind == "quad":
+            q = pos()
+            u, v = (rnd.uniform(-1.5, 1.5), rnd.uniform(-0.3, 0.3), rnd.uniform(-1.5, 1.5)), (rnd.uniform(-0.3, 0.3), rnd.uniform(0.3, 1.5), rnd.uniform(-0.3, 0.3))
+            return [s.quad(q, u, v, m)]
+        if kind == "cube":
+            return [s.list(cube(m))] if rnd.random() < 0.5 else cube(m)
+        items = [r for _ in range(rnd.randint(0, 3)) for r in solid(depth + 1)]
+        g = s.list(items)
+        wrap = rnd.choice(["t", "r", "tr", "rt"])
+        for w in wrap:
+            g = s.translate(g, pos(1.0)) if w == "t" else s.rotate_y(g, rnd.uniform(-80, 80))
+        return [g]
+
+    items = []
+    for _ in range(rnd.randint(1, 9)):
+        roll = rnd.random()
+        if roll < 0.2:
+            boundary = rnd.choice(["sphere", "cube", "framed"])
+            if boundary == "sphere":
+                b = s.sphere(pos(), rnd.uniform(0.5, 3.0), mats[0])
+            elif boundary == "cube":
+                b = s.list(cube(mats[0]))
+            else:
+                b = s.translate(s.rotate_y(s.list(cube(mats[0])), rnd.uniform(-60, 60)), pos(1.0))
+            items.append(s.medium(b, rnd.choice([0.05, 0.5, 3.0]), rnd.random(), rnd.random(), rnd.random()))
+        else:
+            new = solid(0)
+            items.extend(new)
+            if rnd.random() < 0.15 and new:  # an exact copy right after, or at the end: ties
+                dup = new[0]
+                if dup.kind == rt.RT_HITTABLE_SPHERE:
+                    sp = s.spheres[dup.index]
+                    items.insert(rnd.randint(0, len(items)), s.sphere((sp.center.x, sp.center.y, sp.center.z), sp.radius, rnd.choice(mats)))
+                elif dup.kind == rt.RT_HITTABLE_QUAD:
+                    qd = s.quads[dup.index]
+                    items.insert(rnd.randint(0, len(items)), s.quad(qd.q.tuple(), qd.u.tuple(), qd.v.tuple(), rnd.choice(mats)))
+    return s.finish(s.list(items))

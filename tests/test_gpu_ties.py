@@ -89,3 +89,25 @@ def test_frames_inside_frames(rt, oracle, gpu):
     st = rt.DeviceScene(scene).stats()
     assert st["ordered"] == 1 and st["max_instance_depth"] >= 3
     check(rt, oracle, scene, "nested frames")
+
+
+def test_random_object_graphs(rt, oracle, gpu):
+    """Fuzz: 40 random scenes (tests/custom_scenes.py::random_scene), each rendered by whichever walks it supports."""
+    lib = rt.amd_lib()
+    cam = scene_cases.build(rt, "ragged_cornell_37x37_4spp")
+    params = rt.render_params(seed=5)
+    ordered_seen = 0
+    try:
+        for seed in range(40):
+            scene = custom_scenes.random_scene(cam, seed)
+            want = oracle.render(scene, params)
+            for ordered in (1, 0):
+                lib.rt_debug_set_traversal(ordered, 0)
+                ds = rt.DeviceScene(scene)
+                ordered_seen += ds.stats()["ordered"]
+                got = ds.render(params)
+                bad = np.flatnonzero(bits(got) != bits(want))
+                assert bad.size == 0, f"random scene {seed}, ordered={ds.stats()['ordered']}: {bad.size} of {want.size} values differ"
+    finally:
+        lib.rt_debug_set_traversal(1, 0)
+    assert ordered_seen >= 30
