@@ -847,7 +847,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (ok) {
                         cur_tmax = root;
                         tmax32 = ORDERED ? __double2float_ru(root) : (float)root;
-                        if (!HAS_MEDIA || (mode & 3u) == 0) { best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
+                        if (!HAS_MEDIA || (mode & 3u) == 0) { if (HAS_MEDIA) best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
                         else mode |= 0x100u;
                     }
                 }
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
                     cur_tmax = t;
                     tmax32 = ORDERED ? __double2float_ru(t) : (float)t;
-                    if (!HAS_MEDIA || (mode & 3u) == 0) { best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
+                    if (!HAS_MEDIA || (mode & 3u) == 0) { if (HAS_MEDIA) best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
                     else mode |= 0x100u;
                 }
                 prim_cur = prim_end;
@@ -981,7 +981,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 // rebuild the HitRecord in its own frame, then carry it to the world
                 V3 lo = o, ld = d; // all frames are closed at this point: (o, d) is the world ray
                 if (HAS_FRAMES) ray_to_frame(P.insts, best_inst, lo, ld);
-                V3 p = lo + ld * best_t; // Ray::at (src/ray.rs:30-32)
+                // (without media the interval's upper end IS the closest hit's t: one value less to keep per lane)
+                V3 p = lo + ld * (HAS_MEDIA ? best_t : cur_tmax); // Ray::at (src/ray.rs:30-32)
                 V3 outward_normal;
                 uint32_t mat;
                 double u = 0.0, v = 0.0;
