@@ -103,9 +103,12 @@ RT_DEV V3 from(const rt_vec3 &a) { return V3{a.x, a.y, a.z}; }
 
 // ---- frame changes (Translate::hit then RotateY::hit, src/hittable.rs:96-106,:159-188) -------------------
 RT_DEV void apply_instance(const Instance &in, V3 &o, V3 &d) {
-    if (in.flags & INST_TRANSLATE) o = o - ld3(in.offset);
-    if (in.flags & INST_ROTATE) {
-        const double c = in.cos_theta, s = in.sin_theta;
+    // all fields are read up front (one memory round trip, not one per `if (flags & ...)`)
+    const uint32_t flags = in.flags;
+    const V3 offset = ld3(in.offset);
+    const double c = in.cos_theta, s = in.sin_theta;
+    if (flags & INST_TRANSLATE) o = o - offset;
+    if (flags & INST_ROTATE) {
         const double ox = c * o.x - s * o.z, oz = s * o.x + c * o.z;
         const double dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
         o.x = ox; o.z = oz; d.x = dx; d.z = dz;
