@@ -31,6 +31,9 @@ WORKLOADS = {
     "c3": dict(name="cornell box 600x600, 1000 spp, depth 50", scene=6, width=600, aspect=1.0, spp=1000, depth=50),
     "c4": dict(name="final_scene 800x800, 5000 spp, depth 40", scene=8, width=800, aspect=1.0, spp=5000, depth=40,
                earth_image="synthetic:6400x3200"),
+    # BASELINE.json's 8-GPU case (also fits one GPU: the sample buffer is filled and drained 38 times)
+    "c5": dict(name="final_scene 1600x1600, 10000 spp, depth 50", scene=8, width=1600, aspect=1.0, spp=10000, depth=50,
+               earth_image="synthetic:6400x3200"),
 }
 SCENE_SEED = 1
 RENDER_SEED = 1
@@ -219,7 +222,7 @@ def main():
             import oracle_lib  # the CPU restatement: timed here as the baseline, never part of the product path
             cores = oracle_lib.default_threads()
             # a bounded sample, about 10 s of the host's cores: the first spp of the same frame (c1: the whole workload)
-            base_spp = {"c1": 10, "c2": 64, "c3": 256, "c4": 8}[args.workload]
+            base_spp = {"c1": 10, "c2": 64, "c3": 256, "c4": 8, "c5": 2}[args.workload]
             base_spp = min(base_spp, spp)
             t1 = time.perf_counter()
             oracle_lib.render(hs, rt.render_params(seed=RENDER_SEED, sample_end=base_spp), threads=cores)
