@@ -328,10 +328,11 @@ typedef struct rt_debug_node {
 int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity,
                             int64_t *out_count);
 
-/* Test / tuning hook: how scenes created from now on are walked.  ordered = 1 (default): the library's own trees,
- * nearest child first — with media, a sequence of trees and media in the reference's scan order (DESIGN.md "Ordered
- * layout"; a medium inside a Translate / RotateY frame keeps the other walk); 0: every scene walks the reference's tree
- * in the reference's order.  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
+/* Test / tuning hook: how scenes created from now on are walked.  ordered = 2: the library's own trees, nearest child
+ * first — with media, a sequence of trees and media in the reference's scan order (DESIGN.md "Ordered layout"; a medium
+ * inside a Translate / RotateY frame keeps the other walk); 0: every scene walks the reference's tree in the reference's
+ * order; 1 (default): as 2, except for scenes measured faster the other way (a handful of primitives; small scenes with
+ * box-bounded media).  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
  * Affects speed only, never results. */
 int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
 

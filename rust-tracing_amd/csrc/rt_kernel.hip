@@ -1401,7 +1401,8 @@ struct Tuning {
     int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     int refit = 1;   // 0: walk the reference's own (looser) boxes
-    int ordered = 1; // 0: always walk the threaded records in the reference's order (scenes created afterwards)
+    int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
+                     // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     OrderedOptions ordered_options;
     size_t sample_buffer_bytes = (size_t)16 << 30;
@@ -1745,13 +1746,28 @@ int64_t rt_out_size(int32_t width, int32_t height, int32_t out_layout, int32_t s
     return -1;
 }
 
+// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py), own trees vs reference
+// order, Msamples/s: two_spheres 3978 / 4813, earth 15970 / 19317, two_perlin_spheres 2349 / 2651, simple_light 3060 /
+// 3322 (1-4 primitives: a tree and a stack are overhead); quads 15790 / 14393, cornell_box 2206 / 1967, random_balls 3557 /
+// 2038, final_scene 821 / 624; cornell_smoke 496 / 736 (18 quads, and two media whose rotated-box boundaries are walked as
+// trees of their own, twice per visit).
+static bool ordered_walk_pays(const CompiledScene &cs) {
+    const size_t prims = cs.spheres.size() + cs.quads.size();
+    if (prims <= 4) return false;
+    bool general_boundary = false;
+    for (const Node &n : cs.nodes)
+        if ((n.kind & NODE_KIND_MASK) == NK_MEDIUM_ENTER) general_boundary = true;
+    if (general_boundary && prims < 64) return false;
+    return true;
+}
+
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) {
     if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
     *out_scene = nullptr;
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, tuning().refit != 0);
-        if (tuning().ordered) build_ordered(cs, tuning().ordered_options);
+        if (tuning().ordered == 2 || (tuning().ordered == 1 && ordered_walk_pays(cs))) build_ordered(cs, tuning().ordered_options);
     } catch (const CompileError &e) {
         return fail(e.status, e.what());
     } catch (const std::exception &e) {

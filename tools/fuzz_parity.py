@@ -18,7 +18,7 @@ for seed in range(first, first + count):
     for render_seed in (5, 6):
         params = rt.render_params(seed=render_seed)
         want = oracle_lib.render(scene, params)
-        for ordered in (1, 0):
+        for ordered in (2, 0):
             lib.rt_debug_set_traversal(ordered, 0)
             got = rt.DeviceScene(scene).render(params)
             if not np.array_equal(got.view(np.uint64), want.view(np.uint64)):
