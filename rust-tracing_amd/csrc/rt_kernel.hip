@@ -86,6 +86,8 @@ struct KParams {
     const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
     const OSeq *oseq;               // the world frame's sequence of trees and media (rt_layout.h)
     float box_extent;               // the largest |coordinate| of any box of the ordered layout (box_pair_f32's B)
+    const uint4 *aux_image;         // AUX kernels: materials | textures | frames | media | Perlin tables, to copy into the LDS
+    uint32_t aux_bytes, lds_aux_off, aux_off_mats, aux_off_texs, aux_off_insts, aux_off_media, aux_off_perlins;
     uint32_t n_oseq;
     uint32_t o_root;
     uint32_t lds_stack_off;
@@ -198,14 +200,15 @@ RT_DEV double perlin_turbulence(const rt_perlin *pn, V3 p, int depth) {
 RT_DEV double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
 // ---- Texture::value (src/texture.rs) ---------------------------------------------------------------------
-template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, uint32_t tex, double u, double v, V3 p, Counts &cn) {
-    const rt_texture *t = &P.texs[tex];
+template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, const rt_texture *texs, const rt_perlin *perlins, uint32_t tex, double u, double v, V3 p,
+                                              Counts &cn) {
+    const rt_texture *t = &texs[tex];
     while (t->kind == RT_TEXTURE_CHECKER) { // src/texture.rs:59-69
         const int32_t x = f64_as_i32(__builtin_floor(t->inv_scale * p.x));
         const int32_t y = f64_as_i32(__builtin_floor(t->inv_scale * p.y));
         const int32_t z = f64_as_i32(__builtin_floor(t->inv_scale * p.z));
         const int32_t s = (int32_t)((uint32_t)x + (uint32_t)y + (uint32_t)z);
-        t = &P.texs[(s % 2 == 0) ? t->even : t->odd];
+        t = &texs[(s % 2 == 0) ? t->even : t->odd];
     }
     if (t->kind == RT_TEXTURE_SOLID) return from(t->color); // src/texture.rs:32-36
     if (t->kind == RT_TEXTURE_IMAGE) {                      // src/texture.rs:82-92
@@ -220,7 +223,7 @@ template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, uint32_t tex, do
     }
     // RT_TEXTURE_NOISE, src/texture.rs:107-110
     if (COUNT) cn.noise_evals++;
-    const double turb = perlin_turbulence(&P.perlins[t->perlin], p, 7);
+    const double turb = perlin_turbulence(&perlins[t->perlin], p, 7);
     const double s = rt_sin(t->scale * p.z + 10.0 * turb) * 0.5 + 0.5;
     return v3(s, s, s);
 }
@@ -466,7 +469,9 @@ constexpr uint32_t F_ALL = 31u;
 // LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = + sphere table; 3 = + quad table
 // ORDERED: walk the compiler's own trees nearest child first (scenes without a ConstantMedium), else the threaded
 // records in the reference's order
-template <bool COUNT, int LDS, int THREADS, uint32_t FEAT, bool ORDERED>
+// AUX: the small tables (materials, textures, frames, media, Perlin) are copied into the LDS too — for scenes whose big
+// tables do not fit there, so that a hit's material -> texture -> noise chain is not three trips to memory
+template <bool COUNT, int LDS, int THREADS, uint32_t FEAT, bool ORDERED, bool AUX = false>
 __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
                    HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
@@ -493,6 +498,16 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     }
     const Sphere *const sphere_tab = LDS >= 2 ? reinterpret_cast<const Sphere *>(lds_raw + P.lds_off_spheres) : P.spheres;
     const Quad *const quad_tab = LDS == 3 ? reinterpret_cast<const Quad *>(lds_raw + P.lds_off_quads) : P.quads;
+    if constexpr (AUX) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw + P.lds_aux_off);
+        for (uint32_t k = threadIdx.x; k < P.aux_bytes / 16u; k += THREADS) dst[k] = P.aux_image[k];
+        __syncthreads();
+    }
+    const DMaterial *const mats_tab = AUX ? reinterpret_cast<const DMaterial *>(lds_raw + P.lds_aux_off + P.aux_off_mats) : P.mats;
+    const rt_texture *const texs_tab = AUX ? reinterpret_cast<const rt_texture *>(lds_raw + P.lds_aux_off + P.aux_off_texs) : P.texs;
+    const Instance *const inst_tab = AUX ? reinterpret_cast<const Instance *>(lds_raw + P.lds_aux_off + P.aux_off_insts) : P.insts;
+    const Medium *const media_tab = AUX ? reinterpret_cast<const Medium *>(lds_raw + P.lds_aux_off + P.aux_off_media) : P.media;
+    const rt_perlin *const perlin_tab = AUX ? reinterpret_cast<const rt_perlin *>(lds_raw + P.lds_aux_off + P.aux_off_perlins) : P.perlins;
     // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree) is parked in global
     // memory (touched 0.3-2.6 times per sample; the LDS is worth more as scene storage)
     double *const world_slot = P.world_slots + gtid;
@@ -906,17 +921,17 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const bool leaving = node == NODE_FRAME_EXIT;
                     const size_t ws = P.n_threads;
                     if (leaving) {
-                        cur_inst = P.insts[cur_inst].parent;
+                        cur_inst = inst_tab[cur_inst].parent;
                         o = v3(world_slot[0], world_slot[ws], world_slot[2 * ws]);
                         d = v3(world_slot[3 * ws], world_slot[4 * ws], world_slot[5 * ws]);
-                        ray_to_frame(P.insts, cur_inst, o, d);
+                        ray_to_frame(inst_tab, cur_inst, o, d);
                     } else {
                         if (COUNT) cn.instance_enters++;
                         if (cur_inst < 0) { // leaving the world frame: park the world ray
                             world_slot[0] = o.x; world_slot[ws] = o.y; world_slot[2 * ws] = o.z;
                             world_slot[3 * ws] = d.x; world_slot[4 * ws] = d.y; world_slot[5 * ws] = d.z;
                         }
-                        apply_instance(P.insts[node], o, d);
+                        apply_instance(inst_tab[node], o, d);
                         cur_inst = (int32_t)node;
                         stack[sp * THREADS] = (StackT)S_EXIT;
                         sp++;
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     refresh_ray32();
                     a = len2(d);
                     if (leaving) o_next(false, 0u);
-                    else { node = P.insts[cur_inst].root; stage = ST_BOX; }
+                    else { node = inst_tab[cur_inst].root; stage = ST_BOX; }
                 }
             } else
             if (stage == ST_OTHER) {
@@ -938,15 +953,15 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         world_slot[0] = o.x; world_slot[ws] = o.y; world_slot[2 * ws] = o.z;
                         world_slot[3 * ws] = d.x; world_slot[4 * ws] = d.y; world_slot[5 * ws] = d.z;
                     }
-                    apply_instance(P.insts[na], o, d);
+                    apply_instance(inst_tab[na], o, d);
                     cur_inst = (int32_t)na;
                     node = node + 1;
                 } else if (HAS_FRAMES && kind == NK_INST_EXIT) {
-                    cur_inst = P.insts[na].parent;
+                    cur_inst = inst_tab[na].parent;
                     const size_t ws = P.n_threads;
                     o = v3(world_slot[0], world_slot[ws], world_slot[2 * ws]);
                     d = v3(world_slot[3 * ws], world_slot[4 * ws], world_slot[5 * ws]);
-                    ray_to_frame(P.insts, cur_inst, o, d);
+                    ray_to_frame(inst_tab, cur_inst, o, d);
                     node = node + 1;
                 } else if (HAS_MEDIA && kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
                     if (COUNT) cn.medium_visits++;
@@ -955,12 +970,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     cur_tmax = INF;
                     node = node + 1;
                 } else if (HAS_MEDIA && kind == NK_MEDIUM_SPHERE) {
-                    const Medium md = P.media[na];
+                    const Medium md = media_tab[na];
                     const Sphere *s = &sphere_tab[md.first_node];
                     medium_sphere_hit(na, ld3(s->center), ld3(s->center_vec), (s->seq_moving & 1u) != 0, s->radius, md.neg_inv_density);
                     node = nd.skip;
                 } else if (HAS_MEDIA) { // NK_MEDIUM_EXIT
-                    if (medium_boundary_done(na, P.media[na].neg_inv_density)) node = P.media[na].first_node;
+                    if (medium_boundary_done(na, media_tab[na].neg_inv_density)) node = media_tab[na].first_node;
                     else node = node + 1;
                 }
                 if (kind == NK_INST_ENTER || kind == NK_INST_EXIT) {
@@ -983,7 +998,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 bool path_done = false;
                 // rebuild the HitRecord in its own frame, then carry it to the world
                 V3 lo = o, ld = d; // all frames are closed at this point: (o, d) is the world ray
-                if (HAS_FRAMES) ray_to_frame(P.insts, best_inst, lo, ld);
+                if (HAS_FRAMES) ray_to_frame(inst_tab, best_inst, lo, ld);
                 // (without media the interval's upper end IS the closest hit's t: one value less to keep per lane)
                 V3 p = lo + ld * (HAS_MEDIA ? best_t : cur_tmax); // Ray::at (src/ray.rs:30-32)
                 V3 outward_normal;
@@ -1002,7 +1017,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const Quad *qd = &quad_tab[pi];
                     outward_normal = ld3(qd->normal);
                     mat = qd->material;
-                    if (HAS_TEXTURES && P.mats[mat].needs_uv) {
+                    if (HAS_TEXTURES && mats_tab[mat].needs_uv) {
                         const V3 php = p - ld3(qd->q);
                         const V3 qw = ld3(qd->w);
                         u = dot(qw, cross(php, ld3(qd->v)));
@@ -1010,9 +1025,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                 } else { // ConstantMedium: normal := r.direction (src/constant_medium.rs:52-58)
                     outward_normal = ld;
-                    mat = P.media[pi].phase_material;
+                    mat = media_tab[pi].phase_material;
                 }
-                const DMaterial *m = &P.mats[mat];
+                const DMaterial *m = &mats_tab[mat];
                 if (HAS_TEXTURES && uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
                     const double PI = 3.14159265358979323846264338327950288;
                     const double theta = rt_acos(-outward_normal.y);
@@ -1023,7 +1038,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 // HitRecord::new (src/hittable.rs:22-37)
                 const bool front_face = dot(ld, outward_normal) < 0.0;
                 V3 normal = front_face ? outward_normal : -outward_normal;
-                if (HAS_FRAMES) hit_to_world(P.insts, best_inst, p, normal);
+                if (HAS_FRAMES) hit_to_world(inst_tab, best_inst, p, normal);
 
                 const uint32_t mk = m->kind;
                 // Every material that reads a texture reads exactly one, after its random draws (textures draw
@@ -1035,7 +1050,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
                 PROF_MARK(7);
                 if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) {
-                    if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, m->texture, u, v, p, cn);
+                    if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, texs_tab, perlin_tab, m->texture, u, v, p, cn);
                     else tex = ld3(m->albedo); // every texture is a SolidColor (src/texture.rs:32-36): the colour was copied here
                 }
                 V3 attenuation = tex;
@@ -1465,6 +1480,8 @@ struct rt_scene {
     DeviceArray<OSeq> oseq;                      // ... and the world frame's sequence
     uint32_t n_oseq = 0;
     float box_extent = 0.0f;                     // largest |coordinate| of any box of the ordered layout
+    DeviceArray<uint4> aux_image;                // materials | textures | frames | media | Perlin for the AUX kernels (0 bytes: not used)
+    uint32_t aux_bytes = 0, aux_off[5] = {0, 0, 0, 0, 0};
     uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
     rt_scene_stats stats{};
     std::mutex mu;
@@ -1491,8 +1508,10 @@ uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
     (void)ordered;
     return F_ALL;
 }
-const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered) {
+const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
 #define RT_PICK(L, T, F, O) (counted ? (const void *)path_kernel<true, L, T, F, O> : (const void *)path_kernel<false, L, T, F, O>)
+    if (ordered && lds == 0 && aux)
+        return counted ? (const void *)path_kernel<true, 0, GLOBAL_THREADS, F_ALL, true, true> : (const void *)path_kernel<false, 0, GLOBAL_THREADS, F_ALL, true, true>;
     if (ordered) {
         if (lds == 3) {
             if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true);
@@ -1520,7 +1539,9 @@ size_t stack_bytes(const rt_scene *s, int lds) {
 }
 size_t prof_bytes(int lds) { return (size_t)((lds ? LDS_THREADS : GLOBAL_THREADS) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
 size_t seq_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 15u) & ~(size_t)15u; }
-size_t prof_offset(const rt_scene *s, int lds) { return seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u); }
+size_t aux_offset(const rt_scene *s, int lds) { return (seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u) + 15u) & ~(size_t)15u; }
+bool aux_in_lds(const rt_scene *s, int lds) { return lds == 0 && s->aux_bytes != 0; }
+size_t prof_offset(const rt_scene *s, int lds) { return aux_offset(s, lds) + (aux_in_lds(s, lds) ? s->aux_bytes : 0u); }
 size_t dynamic_lds_bytes(const rt_scene *s, int lds, bool counted) {
     return prof_offset(s, lds) + (counted ? prof_bytes(lds) : 0);
 }
@@ -1555,7 +1576,7 @@ void free_scene(rt_scene *s) {
     }
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
-    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr); (void)hipFree(s->aux_image.ptr);
     delete s;
 }
 
@@ -1673,6 +1694,9 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.box_extent = scene->box_extent;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
+    K.aux_image = scene->aux_image.ptr; K.aux_bytes = scene->aux_bytes; K.lds_aux_off = (uint32_t)aux_offset(scene, lds);
+    K.aux_off_mats = scene->aux_off[0]; K.aux_off_texs = scene->aux_off[1]; K.aux_off_insts = scene->aux_off[2];
+    K.aux_off_media = scene->aux_off[3]; K.aux_off_perlins = scene->aux_off[4];
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
@@ -1701,7 +1725,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
         {
             void *args[] = {(void *)&K};
-            HIP_TRY(hipLaunchKernel(kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
+            HIP_TRY(hipLaunchKernel(kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered, aux_in_lds(scene, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
         }
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(256), 0, stream, K);
@@ -1856,18 +1880,6 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
             for (int l = s->lds_level + 1; l < 4; ++l) s->lds_prefix_bytes[l] = 0;
         }
     }
-    for (int lds = 0; lds < 4; ++lds)
-        for (int counted = 0; counted < 2; ++counted) {
-            if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
-            const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered);
-            const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-            const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
-            if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            int b = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
-            s->blocks_per_cu[lds][counted] = b;
-        }
-
     std::vector<DMaterial> mats(cs.materials.size());
     for (size_t i = 0; i < mats.size(); ++i) {
         const rt_material &m = cs.materials[i];
@@ -1886,6 +1898,41 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
         d.ir = m.ir;
         mats[i] = d;
     }
+
+    // AUX image (path_kernel's AUX): the small tables, for ordered scenes whose big tables stay in global memory
+    {
+        auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
+        const size_t o_mats = 0, o_texs = align16(o_mats + mats.size() * sizeof(DMaterial)),
+                     o_insts = align16(o_texs + cs.textures.size() * sizeof(rt_texture)),
+                     o_media = align16(o_insts + cs.instances.size() * sizeof(Instance)),
+                     o_perlins = align16(o_media + cs.media.size() * sizeof(Medium)),
+                     total = align16(o_perlins + cs.perlins.size() * sizeof(rt_perlin));
+        if (s->ordered && s->lds_level == 0 && total > 0 && total <= 24 * 1024) {
+            std::vector<uint4> img(total / 16);
+            unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
+            if (!mats.empty()) memcpy(base + o_mats, mats.data(), mats.size() * sizeof(DMaterial));
+            if (!cs.textures.empty()) memcpy(base + o_texs, cs.textures.data(), cs.textures.size() * sizeof(rt_texture));
+            if (!cs.instances.empty()) memcpy(base + o_insts, cs.instances.data(), cs.instances.size() * sizeof(Instance));
+            if (!cs.media.empty()) memcpy(base + o_media, cs.media.data(), cs.media.size() * sizeof(Medium));
+            if (!cs.perlins.empty()) memcpy(base + o_perlins, cs.perlins.data(), cs.perlins.size() * sizeof(rt_perlin));
+            int urc = upload(s->aux_image, img);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+            s->aux_bytes = (uint32_t)total;
+            s->aux_off[0] = (uint32_t)o_mats; s->aux_off[1] = (uint32_t)o_texs; s->aux_off[2] = (uint32_t)o_insts;
+            s->aux_off[3] = (uint32_t)o_media; s->aux_off[4] = (uint32_t)o_perlins;
+        }
+    }
+    for (int lds = 0; lds < 4; ++lds)
+        for (int counted = 0; counted < 2; ++counted) {
+            if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
+            const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered, aux_in_lds(s, lds));
+            const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+            const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            int b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
+            s->blocks_per_cu[lds][counted] = b;
+        }
 
     int rc = RT_OK;
     if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->oseq, cs.oseq)) != RT_OK ||
