@@ -298,11 +298,20 @@ struct OPair {
     uint32_t c0, c1;
 };
 template <int LDS> RT_DEV OPair load_opair(const KParams &P, const unsigned char *lds, uint32_t id, uint32_t offx, uint32_t offy, uint32_t offz) {
-    const unsigned char *base = LDS != 0 ? lds : reinterpret_cast<const unsigned char *>(P.oimage);
-    const float4 qx = *reinterpret_cast<const float4 *>(base + offx + id * 16u);
-    const float4 qy = *reinterpret_cast<const float4 *>(base + offy + id * 16u);
-    const float4 qz = *reinterpret_cast<const float4 *>(base + offz + id * 16u);
-    const uint2 r = *reinterpret_cast<const uint2 *>(base + 6u * P.lds_off_node_b + id * 8u);
+    float4 qx, qy, qz;
+    uint2 r;
+    if constexpr (LDS != 0) { // seven tables
+        qx = *reinterpret_cast<const float4 *>(lds + offx + id * 16u);
+        qy = *reinterpret_cast<const float4 *>(lds + offy + id * 16u);
+        qz = *reinterpret_cast<const float4 *>(lds + offz + id * 16u);
+        r = *reinterpret_cast<const uint2 *>(lds + 6u * P.lds_off_node_b + id * 8u);
+    } else { // global memory: the same seven pieces side by side in one 128-byte line per record (offsets 0 .. 80, 96)
+        const unsigned char *rec = reinterpret_cast<const unsigned char *>(P.oimage) + (size_t)id * 128u;
+        qx = *reinterpret_cast<const float4 *>(rec + offx);
+        qy = *reinterpret_cast<const float4 *>(rec + offy);
+        qz = *reinterpret_cast<const float4 *>(rec + offz);
+        r = *reinterpret_cast<const uint2 *>(rec + 96);
+    }
     OPair n;
     n.nx = f32x2{qx.x, qx.y}; n.fx = f32x2{qx.z, qx.w};
     n.ny = f32x2{qy.x, qy.y}; n.fy = f32x2{qy.z, qy.w};
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // f32 copies for the conservative box test: origin, 1/d, and the bound E on what rounding the origin to f32
     // can move a slab distance (see the box stage); `degenerate`: some 1/d or E is not finite -> enter every box
     std::conditional_t<ORDERED, RayPair32, Ray32> r32;
-    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b, P.box_extent); else r32 = make_ray32(o, d);
+    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : 16u, P.box_extent); else r32 = make_ray32(o, d);
     float tmin32 = 0, tmax32 = 0;
     uint32_t job = 0;
     int32_t depth = 0;
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     const int32_t w = P.cam.image_width, h = P.cam.image_height;
 
     auto refresh_ray32 = [&]() {
-        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, P.lds_off_node_b, P.box_extent);
+        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : 16u, P.box_extent);
         else r32 = make_ray32(o, d);
     };
     // (the ordered walk's test takes the interval rounded outward; the threaded one has the slack for either rounding)
@@ -1850,8 +1859,15 @@ int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene)
                     for (size_t q = 0; q < 2; ++q) memcpy(base + q * off_b + i * 16, src + (i * 2 + q) * 16, 16);
             }
         }
-        if (cs.ordered) {
-            int urc = upload(s->oimage, tables);
+        if (cs.ordered) { // the global copy: one 128-byte line per record (load_opair<0>)
+            std::vector<uint4> lines(n * 8);
+            unsigned char *dst = reinterpret_cast<unsigned char *>(lines.data());
+            const unsigned char *tab = reinterpret_cast<const unsigned char *>(tables.data());
+            for (size_t i = 0; i < n; ++i) {
+                for (size_t q = 0; q < 6; ++q) memcpy(dst + i * 128 + q * 16, tab + q * off_b + i * 16, 16);
+                memcpy(dst + i * 128 + 96, tab + 6 * off_b + i * 8, 8);
+            }
+            int urc = upload(s->oimage, lines);
             if (urc != RT_OK) { free_scene(s); return urc; }
         }
         s->lds_off_node_b = (uint32_t)off_b;
