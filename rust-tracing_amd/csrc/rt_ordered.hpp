@@ -67,6 +67,7 @@ class OrderedBuilder {
         // the world frame's sequence: trees and media in scan order
         uint32_t need = 1;
         std::vector<OSeq> seq;
+        std::vector<std::pair<uint32_t, uint32_t>> new_first_node; // (medium, index of its boundary sphere in new_spheres_)
         for (const SeqItem &si : sequence_) {
             OSeq o{};
             o.kind = si.kind;
@@ -86,7 +87,7 @@ class OrderedBuilder {
                 o.radius = sp.radius;
                 o.moving = sp.seq_moving & 1u;
                 o.neg_inv_density = cs_.media[si.medium].neg_inv_density;
-                cs_.media[si.medium].first_node = (uint32_t)new_spheres_.size();
+                new_first_node.emplace_back(si.medium, (uint32_t)new_spheres_.size()); // applied only if the build succeeds
                 new_spheres_.push_back(cs_.spheres[old_index]);
             } else {
                 if (frames_[si.frame].empty()) continue; // a boundary without geometry: the medium can never be hit
@@ -103,6 +104,7 @@ class OrderedBuilder {
             }
             seq.push_back(o);
         }
+        // (nothing of cs_ has been touched up to here: a scene that is turned down keeps its threaded layout intact)
         if (need > ORDERED_MAX_STACK || seq.size() > ORDERED_MAX_STEPS) return false;
         if (seq.empty()) { // nothing can be hit: one tree whose root has two empty children
             OSeq o{};
@@ -111,6 +113,7 @@ class OrderedBuilder {
             seq.push_back(o);
         }
         for (size_t i = 0; i < cs_.instances.size(); ++i) cs_.instances[i].root = root_[frame_of_inst_[i]];
+        for (const auto &mf : new_first_node) cs_.media[mf.first].first_node = mf.second;
         cs_.spheres.swap(new_spheres_);
         cs_.quads.swap(new_quads_);
         cs_.onodes.swap(nodes_);

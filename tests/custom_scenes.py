@@ -293,3 +293,19 @@ def random_scene(camera_from, seed):
                     qd = s.quads[dup.index]
                     items.insert(rnd.randint(0, len(items)), s.quad(qd.q.tuple(), qd.u.tuple(), qd.v.tuple(), rnd.choice(mats)))
     return s.finish(s.list(items))
+
+
+def many_media_scene(camera_from, n=40, seed=11):
+    """n solid spheres alternating with n sphere-bounded media in one flat list: 2n + steps of the world sequence, more than
+    the ordered layout's kernel keeps (ORDERED_MAX_STEPS = 64), so the scene compiler turns the ordered layout down and the
+    reference-order walk must find every medium's boundary sphere where the threaded layout put it."""
+    import random
+    rnd = random.Random(seed)
+    s = CustomScene(camera_from, spp=4, depth=6, background=(0.7, 0.8, 1.0))
+    mats = [s.lambertian(rnd.random(), rnd.random(), rnd.random()) for _ in range(5)] + [s.metal(0.8, 0.8, 0.8, 0.1), s.dielectric(1.5)]
+    items = []
+    for _ in range(n):
+        items.append(s.sphere((rnd.uniform(-4, 4), rnd.uniform(-2, 2), rnd.uniform(-4, 4)), rnd.uniform(0.2, 0.6), rnd.choice(mats)))
+        boundary = s.sphere((rnd.uniform(-4, 4), rnd.uniform(-2, 2), rnd.uniform(-4, 4)), rnd.uniform(0.3, 1.2), mats[0])
+        items.append(s.medium(boundary, rnd.choice([0.3, 1.0, 4.0]), rnd.random(), rnd.random(), rnd.random()))
+    return s.finish(s.list(items))

@@ -86,6 +86,25 @@ def test_medium_inside_a_frame_keeps_the_reference_walk(rt, oracle, gpu):
     assert (bits(got) == bits(want)).all()
 
 
+def test_too_many_sequence_steps_fall_back_to_the_reference_walk(rt, oracle, gpu):
+    """81 steps (> ORDERED_MAX_STEPS): the ordered layout is turned down even when asked for; the reference-order walk
+    must see every medium's own boundary sphere."""
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.many_media_scene(cam, 40)
+    lib = rt.amd_lib()
+    params = rt.render_params(seed=3)
+    want = oracle.render(scene, params)
+    try:
+        for ordered in (2, 1, 0):
+            lib.rt_debug_set_traversal(ordered, 0)
+            ds = rt.DeviceScene(scene)
+            assert ds.stats()["ordered"] == 0
+            assert (bits(ds.render(params)) == bits(want)).all(), f"ordered={ordered}"
+    finally:
+        lib.rt_debug_set_traversal(1, 0)
+    check(rt, oracle, custom_scenes.many_media_scene(cam, 20), "41 steps")
+
+
 def test_frames_inside_frames(rt, oracle, gpu):
     cam = scene_cases.build(rt, "quads_64x64_8spp")
     scene = custom_scenes.nested_frames_scene(cam)

@@ -129,6 +129,20 @@ def test_a_medium_inside_a_frame_is_left_to_the_reference_walk(rt):
     assert not lay["ordered"] and len(lay["nodes"]) == 0
 
 
+def test_a_scene_the_ordered_layout_turns_down_is_left_untouched(rt):
+    """More steps than the kernel's sequence table holds (ORDERED_MAX_STEPS): build_ordered gives up — and must not have
+    moved any medium's boundary sphere by then (round-1 bug: first_node was rewritten before the size check)."""
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.many_media_scene(cam, 40)
+    lay = rt.debug_ordered_layout(scene)
+    assert not lay["ordered"] and len(lay["media"]) == 40
+    for m, first in enumerate(lay["media"]):
+        b = scene.spheres[scene.media[m].boundary.index]
+        assert tuple(lay["spheres"][first][:4]) == (b.center.x, b.center.y, b.center.z, b.radius), m
+    # a few steps fewer and the same kind of scene is taken
+    assert rt.debug_ordered_layout(custom_scenes.many_media_scene(cam, 20))["ordered"]
+
+
 def test_random_spheres_tree_is_shallow_and_tight(rt):
     """BASELINE configs 1/2: 485 spheres.  The SAH tree's total child-box area (what a random ray's visit count
     is proportional to) must stay well under the reference tree's."""
