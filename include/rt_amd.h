@@ -41,7 +41,8 @@ typedef enum rt_status {
     RT_ERR_NO_DEVICE = -2,        /* no HIP device / device index out of range          */
     RT_ERR_HIP = -3,              /* a HIP runtime call failed (message has the HIP error string) */
     RT_ERR_OUT_OF_MEMORY = -4,
-    RT_ERR_UNSUPPORTED = -5       /* graph is valid but outside what the device path handles */
+    RT_ERR_UNSUPPORTED = -5,      /* graph is valid but outside what the device path handles */
+    RT_ERR_COMM = -6              /* RCCL is not available or one of its calls failed (message has its error string) */
 } rt_status;
 
 /* Vec3 / Point3 / Color (src/vec3.rs:8-16). */
@@ -255,6 +256,28 @@ int rt_device_count(void);
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene);
 void rt_scene_destroy(rt_scene *scene);
 
+/* Per-scene options (all optional: rt_scene_options_init fills the defaults; results never depend on them, only speed and
+ * memory use do).  They replace the process-wide setters that round 1 used for this. */
+typedef enum rt_walk {
+    RT_WALK_DEFAULT = -1,        /* the library's default (RT_WALK_AUTO unless RT_ORDERED is set in the environment) */
+    RT_WALK_REFERENCE_ORDER = 0, /* the reference's tree in the reference's order (src/bvh.rs:97-108), stackless */
+    RT_WALK_AUTO = 1,            /* the library's own trees where they measured faster (DESIGN.md "Ordered layout") */
+    RT_WALK_OWN_TREES = 2        /* the library's own trees wherever the scene allows it */
+} rt_walk;
+typedef struct rt_scene_options {
+    uint32_t struct_size;        /* sizeof(rt_scene_options): lets the struct grow compatibly */
+    int32_t walk;                /* rt_walk */
+    int32_t leaf_max;            /* own trees: primitives per leaf at most (<= 0: default) */
+    int32_t refit;               /* -1 default (on); 0: keep the reference's boxes; 1: shrink them to the geometry */
+    int32_t use_lds;             /* -1 default (on); 0: gather the scene from global memory even if it fits the LDS */
+    int32_t th_prim, th_other, th_shade, th_box, th_new; /* scheduler thresholds in 64ths of a wave's live lanes; -1: preset */
+    int64_t sample_buffer_bytes; /* per-(scene, stream) sample buffer at most; <= 0: default (2 GiB).  A frame that needs
+                                    more is rendered in several launches over sample sub-ranges (same result). */
+} rt_scene_options;
+void rt_scene_options_init(rt_scene_options *options);
+int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_options *options /* NULL: defaults */,
+                       rt_scene **out_scene);
+
 /* Bytes of device memory the compiled scene occupies, by part (for DESIGN.md's layout table). */
 typedef struct rt_scene_stats {
     uint64_t node_bytes, sphere_bytes, quad_bytes, instance_bytes, medium_bytes, material_bytes,
@@ -293,83 +316,39 @@ int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count,
                              double *d_frame, void *hip_stream);
 
 /* Output stage on the device (reference: color_to_rgb(c / spp), src/renderer.rs:55-58, src/color.rs:12-19):
- * rgb8[(j*w+i)*3+c] = (u8)(256 * clamp((sum * (1/spp))^(1/2.2), 0, 0.999)).  Enqueued on hip_stream. */
+ * rgb8[k] = (u8)(256 * clamp(gamma(sum[k] * (1/spp)), 0, 0.999)) for each of the n_values channel sums, with gamma(x) =
+ * x^(1/2.2) by the fixed algorithm of "Normative definitions" below — the same code the host library runs
+ * (rth_resolve_rgb8), so device and host bytes are identical.  Elementwise: works on a frame (3 * w * h values) and on a
+ * shard's RT_OUT_TILES buffer alike.  Enqueued on hip_stream. */
 int rt_resolve_rgb8_device(int32_t width, int32_t height, int32_t spp, const double *d_frame_sum,
                            uint8_t *d_rgb8, void *hip_stream);
+int rt_resolve_rgb8_values_device(int64_t n_values, int32_t spp, const double *d_sum, uint8_t *d_rgb8, void *hip_stream);
+/* rt_tiles_to_frame_device for gathered RGB8 tile buffers (one byte per value instead of one double). */
+int rt_tiles_to_frame_rgb8_device(int32_t width, int32_t height, int32_t shard_count, const uint8_t *d_gathered,
+                                  uint8_t *d_frame, void *hip_stream);
 
-/* Test hook: evaluates one of the device-side scalar functions of the normative arithmetic over host arrays
- * (out[i] = f(a[i], b[i])), so that tests can compare the GPU's results with the oracle's bit for bit.
- * For the two RNG ops, a[i] and b[i] carry the BIT PATTERNS of the 64-bit stream key and of the draw number
- * (0-based, as in "draw n" of the RNG definition below). */
-typedef enum rt_debug_op {
-    RT_DEBUG_LOG = 1, RT_DEBUG_SIN = 2, RT_DEBUG_ACOS = 3, RT_DEBUG_ATAN2 = 4 /* atan2(a, b) */, RT_DEBUG_POW5 = 5,
-    RT_DEBUG_SQRT = 6, RT_DEBUG_DIV = 7 /* a / b */, RT_DEBUG_MUL_ADD = 8 /* a * b + a, two roundings */,
-    RT_DEBUG_RNG_RANDOM = 9, RT_DEBUG_RNG_RANGE = 10 /* gen_range(-1.0..1.0) */
-} rt_debug_op;
-int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device);
-
-/* Test hook: runs the kernel's conservative f32 box test and the exact f64 slab test on n (ray, box) pairs —
- * rays[i] = (origin xyz, direction xyz), boxes[i] = (lo xyz, hi xyz), interval (tmin, tmax) — and reports, per pair,
- * whether each test enters the box: out_f32_hit bit 0 = the reference-order walk's test, bits 1 and 2 = the ordered walk's
- * pair test with the box in slot 0 / slot 1.  The f32 tests must enter wherever the exact one does (tests/test_gpu_parity.py). */
-int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax,
-                       uint8_t *out_exact_hit, uint8_t *out_f32_hit, int device);
-
-/* Test hook (no GPU needed): runs the scene compiler and returns the records the device would walk — the f64 box each
- * carries after refitting (refit != 0) or as the reference has it (refit == 0), the outward-rounded f32 box actually
- * tested, the threaded links, and the bound of the record's own primitives — so that tests can check the compiler's
- * invariants (links, containment) on the CPU.  out_nodes may be NULL to query the count. */
-typedef struct rt_debug_node {
-    double lo[3], hi[3];           /* box of the record (f64) */
-    float lo32[3], hi32[3];        /* what the kernel tests */
-    double prim_lo[3], prim_hi[3]; /* bound of the leaf's own primitives (+inf/-inf if none) */
-    uint32_t skip, kind, no_bbox, a, b, _pad;
-} rt_debug_node;
-int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity,
-                            int64_t *out_count);
-
-/* Test / tuning hook: how scenes created from now on are walked.  ordered = 2: the library's own trees, nearest child
- * first — with media, a sequence of trees and media in the reference's scan order (DESIGN.md "Ordered layout"; a medium
- * inside a Translate / RotateY frame keeps the other walk); 0: every scene walks the reference's tree in the reference's
- * order; 1 (default): as 2, except for scenes measured faster the other way (a handful of primitives; small scenes with
- * box-bounded media).  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
- * Affects speed only, never results. */
-int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
-
-/* Test hook: the ordered layout the scene compiler builds for `desc` (no device needed).  Set the cap_* fields and
- * the pointers (any may be null: only the counts are returned then).
- * nodes: 16 words per record = two boxes as 6 floats (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi), two child references
- * (kind << 29 | (count - 1) << 26 | index; kind 0 record, 1 spheres, 2 quads, 3 instance, 7 empty), 2 unused.
- * spheres: 9 doubles = center, radius, center_vec, seq, is_moving.  quads: 10 = q, u, v, seq.
- * instances: 8 = offset, sin, cos, parent, flags (1 translate, 2 rotate), root record.
- * steps: the world frame's sequence, 28 words per step = kind (0 tree, 1 medium bounded by one sphere, 2 medium with a
- * boundary tree), a (tree: root record; medium: its index), b (boundary tree's root), moving, box as 6 floats, 2 unused,
- * then as doubles: the boundary sphere's center (3), radius, center_vec (3), and the medium's neg_inv_density.
- * media: per medium, the index of its boundary sphere (kind 1 steps). `root` is the first step's tree. */
-typedef struct rt_debug_ordered {
-    int64_t cap_nodes, cap_spheres, cap_quads, cap_instances, cap_steps, cap_media;
-    int64_t n_nodes, n_spheres, n_quads, n_instances, n_steps, n_media;
-    uint32_t ordered, root, stack_entries, _pad;
-    uint32_t *nodes;
-    double *spheres, *quads, *instances;
-    uint32_t *steps, *media;
-} rt_debug_ordered;
-int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
-
-/* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
- * (box, sphere, quad, other, shade, new-job): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
- * summed over waves; then two parts of the shade stage, cycles only (hit rebuild, unit-sphere rejection sampling — the shade
- * slot itself keeps the remainder). */
-int rt_debug_stage_profile(uint64_t out[24]);
-
-/* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
- * live lanes wait for it (th_new: the path-end / next-job stage); the box loop keeps running while th_box/64 of them are in
- * it; use_lds = 0 forces the
- * scene to be gathered from global memory even when it fits the LDS.  A negative threshold restores the built-in
- * per-scene-class preset; a negative use_lds keeps the current setting.
- * Affects speed only, never results.  Process-wide; not for concurrent use with renders. */
-int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds,
-                        int32_t th_new);
+/* ---- frame-end gather over RCCL / xGMI ----------------------------------------------------------
+ * One communicator handle per rank (= per GPU).  Create it either
+ *   - one process per GPU: rank 0 calls rt_comm_get_unique_id and hands the 128 bytes to the other ranks by whatever
+ *     channel the host program has (MPI, a file, a socket); every rank then calls rt_comm_create;
+ *   - one process, several GPUs: rt_comm_create_all (ncclCommInitAll), then one thread per device;
+ *   - or wrap a communicator the host already owns: rt_comm_adopt(ncclComm_t).
+ * rt_gather_tiles_device brings every rank's RT_OUT_TILES buffer (f64 sums: elem_bytes 8; resolved RGB8: elem_bytes 1)
+ * to `root` in ONE grouped exchange (N - 1 receives on the root, one send per other rank, each on its own xGMI link) into
+ * d_gathered = [rank 0's tiles | rank 1's | ...], every slot rt_out_size(w, h, RT_OUT_TILES, 0, N) elements long — the
+ * layout rt_tiles_to_frame_device / rt_tiles_to_frame_rgb8_device take.  d_gathered is only read on the root.
+ * Enqueued on hip_stream; RCCL is loaded on first use (RT_ERR_COMM if it is not installed). */
+#define RT_COMM_ID_BYTES 128
+typedef struct rt_comm rt_comm; /* opaque */
+int rt_comm_get_unique_id(uint8_t out_id[RT_COMM_ID_BYTES]);
+int rt_comm_create(const uint8_t id[RT_COMM_ID_BYTES], int rank, int n_ranks, int device, rt_comm **out_comm);
+int rt_comm_create_all(int n_devices, const int *devices /* NULL: 0 .. n-1 */, rt_comm **out_comms /* [n_devices] */);
+int rt_comm_adopt(void *nccl_comm, int device, rt_comm **out_comm);
+void rt_comm_destroy(rt_comm *comm);
+int rt_comm_rank(const rt_comm *comm);
+int rt_comm_size(const rt_comm *comm);
+int rt_gather_tiles_device(rt_comm *comm, int32_t width, int32_t height, int32_t elem_bytes, const void *d_tiles,
+                           void *d_gathered, int root, void *hip_stream);
 
 const char *rt_last_error(void);
 const char *rt_version(void);
@@ -378,12 +357,14 @@ const char *rt_version(void);
  *
  * RNG.  The reference draws from rand 0.8.5's thread_rng(), which is OS-seeded and cannot be reproduced
  * (Cargo.toml:10; call sites src/vec3.rs:43-50,:80-81, src/camera.rs:123,:134-135, src/material.rs:94,
- * src/constant_medium.rs:48).  This ABI replaces it by a counter-based generator so that an image is a
- * pure function of (scene, camera, seed):
+ * src/constant_medium.rs:48).  This ABI replaces it by a seeded generator with one stream per camera path, so
+ * that an image is a pure function of (scene, camera, seed):
  *
  *     mix64(z): z ^= z >> 30; z *= 0xBF58476D1CE4E5B9; z ^= z >> 27; z *= 0x94D049BB133111EB; z ^= z >> 31
  *     key(seed, pixel, sample) = mix64( mix64(seed + 0x9E3779B97F4A7C15) ^ ((u64)pixel << 32 | (u32)sample) )
- *     draw n (n = 0, 1, ...) of that path = mix64(key + (n + 1) * 0x9E3779B97F4A7C15)
+ *     stream of that path (RomuDuoJr): x = key, y = mix64(key + 0x9E3779B97F4A7C15); every draw returns x and then
+ *         (x, y) <- (0xD3833E804F4C574B * y,  rotl64(y - x, 27))                  (all arithmetic mod 2^64)
+ *     (round 1 used one splitmix64 output per draw: two 64-bit multiplies; this form needs one — DESIGN.md "RNG")
  *
  * pixel = j * image_width + i (src/renderer.rs:32-33); sample counts from 0.  The draws of one camera path
  * are consumed in the reference's program order (camera px, py, [disk x, y]*, time; then per bounce the

@@ -161,6 +161,28 @@ class SceneOptions(C.Structure):
                 ("max_depth", C.c_int32), ("earth_image", C.c_char_p)]
 
 
+RT_WALK_DEFAULT, RT_WALK_REFERENCE_ORDER, RT_WALK_AUTO, RT_WALK_OWN_TREES = -1, 0, 1, 2
+RT_COMM_ID_BYTES = 128
+
+
+class SceneCreateOptions(C.Structure):
+    """rt_scene_options (per-scene options of rt_scene_create_ex)."""
+    _fields_ = [("struct_size", C.c_uint32), ("walk", C.c_int32), ("leaf_max", C.c_int32), ("refit", C.c_int32),
+                ("use_lds", C.c_int32), ("th_prim", C.c_int32), ("th_other", C.c_int32), ("th_shade", C.c_int32),
+                ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64)]
+
+
+def scene_options(**kw) -> "SceneCreateOptions":
+    """rt_scene_options_init, then the given fields (walk=, leaf_max=, refit=, use_lds=, th_*=, sample_buffer_bytes=)."""
+    o = SceneCreateOptions()
+    amd_lib().rt_scene_options_init(C.byref(o))
+    for k, v in kw.items():
+        if k not in dict(SceneCreateOptions._fields_):
+            raise TypeError(f"rt_scene_options has no field {k}")
+        setattr(o, k, v)
+    return o
+
+
 class DebugNode(C.Structure):
     _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3), ("lo32", C.c_float * 3), ("hi32", C.c_float * 3),
                 ("prim_lo", C.c_double * 3), ("prim_hi", C.c_double * 3), ("skip", C.c_uint32), ("kind", C.c_uint32),
@@ -184,6 +206,24 @@ RT_AMD_SYMBOLS = {
     "rt_out_size": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_tiles_to_frame_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_resolve_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_scene_options_init": (None, [C.c_void_p]),
+    "rt_scene_create_ex": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rt_resolve_rgb8_values_device": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_tiles_to_frame_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "rt_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "rt_comm_adopt": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_comm_destroy": (None, [C.c_void_p]),
+    "rt_comm_rank": (C.c_int, [C.c_void_p]),
+    "rt_comm_size": (C.c_int, [C.c_void_p]),
+    "rt_gather_tiles_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "rt_last_error": (C.c_char_p, []),
+    "rt_version": (C.c_char_p, []),
+}
+
+# every symbol include/rt_amd_debug.h declares (test and tuning hooks; not part of the drop-in boundary)
+RT_AMD_DEBUG_SYMBOLS = {
     "rt_debug_eval": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.c_int]),
     "rt_debug_box_tests": (C.c_int, [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
@@ -194,8 +234,6 @@ RT_AMD_SYMBOLS = {
     "rt_debug_set_traversal": (C.c_int, [C.c_int32, C.c_int32]),
     "rt_debug_ordered_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_debug_set_tuning": (C.c_int, [C.c_int32] * 6),
-    "rt_last_error": (C.c_char_p, []),
-    "rt_version": (C.c_char_p, []),
 }
 
 RT_DEBUG_LOG, RT_DEBUG_SIN, RT_DEBUG_ACOS, RT_DEBUG_ATAN2, RT_DEBUG_POW5, RT_DEBUG_SQRT, RT_DEBUG_DIV, \
@@ -328,7 +366,7 @@ def amd_lib():
         if not path.exists():
             raise RtError(f"{path} is missing: the HIP renderer is not built and there is no fallback; "
                           "run `python -c 'import __graft_entry__ as g; g.build()'`")
-        _amd_lib = _bind(C.CDLL(str(path), mode=C.RTLD_GLOBAL), RT_AMD_SYMBOLS)
+        _amd_lib = _bind(_bind(C.CDLL(str(path), mode=C.RTLD_GLOBAL), RT_AMD_SYMBOLS), RT_AMD_DEBUG_SYMBOLS)
     return _amd_lib
 
 
@@ -396,12 +434,18 @@ def out_size(width, height, out_layout=RT_OUT_FRAME, shard_index=0, shard_count=
 class DeviceScene:
     """rt_scene handle: the compiled scene resident in one GPU's HBM."""
 
-    def __init__(self, host_scene: HostScene, device: int = 0):
+    def __init__(self, host_scene: HostScene, device: int = 0, options: "SceneCreateOptions | None" = None, **option_fields):
         lib = amd_lib()
         self.host_scene = host_scene  # keeps desc memory alive during create
         self.device = device
         handle = C.c_void_p()
-        _check(lib.rt_scene_create(C.byref(host_scene.desc), device, C.byref(handle)), "rt_scene_create")
+        if option_fields:
+            assert options is None
+            options = scene_options(**option_fields)
+        if options is None:
+            _check(lib.rt_scene_create(C.byref(host_scene.desc), device, C.byref(handle)), "rt_scene_create")
+        else:
+            _check(lib.rt_scene_create_ex(C.byref(host_scene.desc), device, C.byref(options), C.byref(handle)), "rt_scene_create_ex")
         self._handle = handle
 
     def stats(self) -> dict:
@@ -455,6 +499,56 @@ def tiles_to_frame_device(width, height, shard_count, d_gathered_ptr: int, d_fra
 def resolve_rgb8_device(width, height, spp, d_frame_ptr: int, d_rgb8_ptr: int, stream: int = 0):
     _check(amd_lib().rt_resolve_rgb8_device(width, height, spp, C.c_void_p(d_frame_ptr), C.c_void_p(d_rgb8_ptr),
                                             C.c_void_p(stream)), "rt_resolve_rgb8_device")
+
+
+def resolve_rgb8_values_device(n_values, spp, d_sum_ptr: int, d_rgb8_ptr: int, stream: int = 0):
+    _check(amd_lib().rt_resolve_rgb8_values_device(n_values, spp, C.c_void_p(d_sum_ptr), C.c_void_p(d_rgb8_ptr),
+                                                   C.c_void_p(stream)), "rt_resolve_rgb8_values_device")
+
+
+def tiles_to_frame_rgb8_device(width, height, shard_count, d_gathered_ptr: int, d_frame_ptr: int, stream: int = 0):
+    _check(amd_lib().rt_tiles_to_frame_rgb8_device(width, height, shard_count, C.c_void_p(d_gathered_ptr),
+                                                   C.c_void_p(d_frame_ptr), C.c_void_p(stream)),
+           "rt_tiles_to_frame_rgb8_device")
+
+
+class Comm:
+    """rt_comm: one RCCL communicator handle of this rank (include/rt_amd.h "frame-end gather")."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * RT_COMM_ID_BYTES)()
+        _check(amd_lib().rt_comm_get_unique_id(buf), "rt_comm_get_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, unique_id: bytes, rank: int, n_ranks: int, device: int) -> "Comm":
+        assert len(unique_id) == RT_COMM_ID_BYTES
+        buf = (C.c_uint8 * RT_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _check(amd_lib().rt_comm_create(buf, rank, n_ranks, device, C.byref(h)), "rt_comm_create")
+        return cls(h)
+
+    rank = property(lambda self: amd_lib().rt_comm_rank(self._handle))
+    size = property(lambda self: amd_lib().rt_comm_size(self._handle))
+
+    def gather_tiles(self, width, height, elem_bytes, d_tiles_ptr: int, d_gathered_ptr: int, root: int = 0, stream: int = 0):
+        _check(amd_lib().rt_gather_tiles_device(self._handle, width, height, elem_bytes, C.c_void_p(d_tiles_ptr),
+                                                C.c_void_p(d_gathered_ptr), root, C.c_void_p(stream)), "rt_gather_tiles_device")
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            amd_lib().rt_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def resolve_rgb8_host(width, height, spp, sums):

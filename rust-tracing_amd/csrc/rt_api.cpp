@@ -1,0 +1,662 @@
+// rt_api.cpp — the host side of librt_amd: the C ABI of include/rt_amd.h (scene upload, render launches, frame-end
+// helpers).  Plain C++ over the HIP runtime API; the kernels live in rt_kernel.hip and are reached through rt_kernels.h.
+#include "rt_api.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace rtapi;
+
+namespace rtapi {
+
+thread_local std::string g_last_error;
+std::mutex g_stage_profile_mu;
+unsigned long long g_stage_profile[PROF_SLOTS * 3] = {0};
+
+int fail(int status, const std::string &msg) {
+    g_last_error = msg;
+    return status;
+}
+
+Tuning::Tuning() {
+    auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
+    env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab);
+    if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
+    if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
+    if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
+    if (const char *e = getenv("RT_SAH_INSTANCE")) ordered_options.cost_instance = atof(e);
+    if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
+}
+namespace {
+std::mutex g_tuning_mu;
+Tuning &tuning_locked() { static Tuning t; return t; } // call with g_tuning_mu held
+} // namespace
+Tuning tuning_snapshot() {
+    std::lock_guard<std::mutex> lock(g_tuning_mu);
+    return tuning_locked();
+}
+void tuning_update(void (*fn)(Tuning &, const void *), const void *arg) {
+    std::lock_guard<std::mutex> lock(g_tuning_mu);
+    fn(tuning_locked(), arg);
+}
+
+} // namespace rtapi
+
+namespace {
+
+uint64_t host_mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return s->lds_prefix_bytes[lds]; }
+// the LDS image, then (ordered walk) the per-lane stacks: 2-byte entries beside an LDS-resident scene, else 4-byte
+size_t stack_bytes(const rt_scene *s, int lds) {
+    if (!s->ordered) return 0;
+    return (size_t)s->o_stack * (lds ? (size_t)LDS_THREADS * 2u : (size_t)GLOBAL_THREADS * 4u);
+}
+size_t prof_bytes(int lds) { return (size_t)((lds ? LDS_THREADS : GLOBAL_THREADS) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
+size_t seq_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 15u) & ~(size_t)15u; }
+size_t aux_offset(const rt_scene *s, int lds) { return (seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u) + 15u) & ~(size_t)15u; }
+bool aux_in_lds(const rt_scene *s, int lds) { return lds == 0 && s->aux_bytes != 0; }
+size_t prof_offset(const rt_scene *s, int lds) { return aux_offset(s, lds) + (aux_in_lds(s, lds) ? s->aux_bytes : 0u); }
+size_t dynamic_lds_bytes(const rt_scene *s, int lds, bool counted) {
+    return prof_offset(s, lds) + (counted ? prof_bytes(lds) : 0);
+}
+
+template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
+    dst.bytes = src.size() * sizeof(T);
+    // never hand the kernel a null table: allocate at least one element
+    const size_t alloc = dst.bytes ? dst.bytes : sizeof(T);
+    HIP_TRY(hipMalloc((void **)&dst.ptr, alloc));
+    if (dst.bytes) HIP_TRY(hipMemcpy(dst.ptr, src.data(), dst.bytes, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(dst.ptr, 0, alloc));
+    return RT_OK;
+}
+
+bool texture_needs_uv(const std::vector<rt_texture> &texs, int32_t t, int depth = 0) {
+    if (t < 0 || depth > 16) return false;
+    const rt_texture &x = texs[(size_t)t];
+    if (x.kind == RT_TEXTURE_IMAGE) return true;
+    if (x.kind == RT_TEXTURE_CHECKER) return texture_needs_uv(texs, x.even, depth + 1) || texture_needs_uv(texs, x.odd, depth + 1);
+    return false;
+}
+
+void free_scene(rt_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (auto &kv : s->workspaces) {
+        (void)hipFree(kv.second.att_stack);
+        (void)hipFree(kv.second.samples);
+        (void)hipFree(kv.second.world_slots);
+        (void)hipFree(kv.second.job_counter);
+        (void)hipFree(kv.second.counters);
+    }
+    (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
+    (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
+    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr); (void)hipFree(s->aux_image.ptr);
+    delete s;
+}
+
+int64_t tiles_total(int32_t w, int32_t h) {
+    return (int64_t)((w + RT_TILE_W - 1) / RT_TILE_W) * ((h + RT_TILE_H - 1) / RT_TILE_H);
+}
+int64_t tiles_local(int32_t w, int32_t h, int32_t shard_index, int32_t shard_count) {
+    return (tiles_total(w, h) - shard_index + shard_count - 1) / shard_count;
+}
+
+int normalise_params(const rt_camera *cam, rt_render_params &p) {
+    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty image");
+    if ((int64_t)cam->image_width * cam->image_height > 0x7fffffffll)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: image has more than 2^31 pixels");
+    if (p.sample_end <= 0) p.sample_end = cam->samples_per_pixel;
+    if (p.max_depth <= 0) p.max_depth = cam->max_depth;
+    if (p.shard_count <= 0) p.shard_count = 1;
+    if (p.sample_begin < 0 || p.sample_end < p.sample_begin) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: bad sample range");
+    if (p.shard_index < 0 || p.shard_index >= p.shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: shard_index out of range");
+    if (p.out_layout != RT_OUT_FRAME && p.out_layout != RT_OUT_TILES) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: unknown out_layout");
+    if (p.max_depth <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: max_depth must be positive");
+    return RT_OK;
+}
+
+// the process defaults of this moment with the scene's own options (rt_scene_create_ex) on top
+Tuning effective_tuning(const rt_scene *scene) {
+    Tuning tn = tuning_snapshot();
+    const rt_scene_options &o = scene->options;
+    if (o.use_lds >= 0) tn.use_lds = o.use_lds;
+    const int32_t th[5] = {o.th_prim, o.th_other, o.th_shade, o.th_box, o.th_new};
+    for (int k = 0; k < 5; ++k)
+        if (th[k] >= 0 && tn.forced[k] < 0) tn.forced[k] = th[k];
+    if (o.sample_buffer_bytes > 0) tn.sample_buffer_bytes = (size_t)o.sample_buffer_bytes;
+    return tn;
+}
+
+constexpr size_t MAX_WORKSPACES = 4; // per scene: one per stream in use; beyond that the idle ones are released
+
+int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, double *d_out, hipStream_t stream,
+                  rt_counters *out_counters) {
+    int rc = normalise_params(camera, p);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    const bool counted = out_counters != nullptr;
+    const int64_t n_local = tiles_local(camera->image_width, camera->image_height, p.shard_index, p.shard_count);
+    const int64_t n_samples_total = (int64_t)p.sample_end - p.sample_begin;
+    if (n_local <= 0 || n_samples_total <= 0) {
+        if (out_counters) *out_counters = rt_counters{};
+        return RT_OK;
+    }
+    const Tuning tn = effective_tuning(scene);
+
+    // samples per launch: bounded by the sample buffer and by the 32-bit job index
+    const int64_t bytes_per_sample_row = n_local * 64 * 3 * (int64_t)sizeof(double);
+    int64_t chunk = (int64_t)(tn.sample_buffer_bytes / (size_t)bytes_per_sample_row);
+    const int64_t max_by_index = ((int64_t)1 << 31) / (n_local * 64);
+    if (chunk > max_by_index) chunk = max_by_index;
+    if (chunk > n_samples_total) chunk = n_samples_total;
+    if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
+
+    const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
+    const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+    const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
+    const size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
+    // persistent grid: every resident wave pulls jobs until none are left
+    int64_t grid = (int64_t)scene->n_cus * bpc;
+    const int64_t waves_per_block = threads / 64;
+    const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_GRAB * waves_per_block - 1) / (MIN_JOBS_PER_GRAB * waves_per_block);
+    if (grid > max_useful) grid = max_useful;
+    if (grid < 1) grid = 1;
+    const uint32_t n_threads = (uint32_t)(grid * threads);
+
+    Workspace ws;
+    {
+        std::lock_guard<std::mutex> lock(scene->mu);
+        if (scene->workspaces.find(stream) == scene->workspaces.end() && scene->workspaces.size() >= MAX_WORKSPACES) {
+            // a new stream and the table is full: release the others' buffers once their work has drained
+            for (auto &kv : scene->workspaces) {
+                (void)hipStreamSynchronize(kv.first); // (a stream that no longer exists: nothing of it is in flight)
+                (void)hipFree(kv.second.att_stack); (void)hipFree(kv.second.samples); (void)hipFree(kv.second.world_slots);
+                (void)hipFree(kv.second.job_counter); (void)hipFree(kv.second.counters);
+            }
+            (void)hipGetLastError();
+            scene->workspaces.clear();
+        }
+        Workspace &w = scene->workspaces[stream];
+        const size_t need_att = ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double); // + a light's emitted colour
+        if (need_att / sizeof(double) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the attenuation stack's 32-bit indices");
+        size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+        if (w.att_bytes < need_att || w.sample_bytes < need_samples) HIP_TRY(hipStreamSynchronize(stream));
+        if (w.att_bytes < need_att) {
+            if (w.att_stack) HIP_TRY(hipFree(w.att_stack));
+            w.att_stack = nullptr; w.att_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&w.att_stack, need_att));
+            w.att_bytes = need_att;
+        }
+        const size_t need_world = (size_t)6 * n_threads * sizeof(double);
+        if (w.world_bytes < need_world) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (w.world_slots) HIP_TRY(hipFree(w.world_slots));
+            w.world_slots = nullptr; w.world_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&w.world_slots, need_world));
+            w.world_bytes = need_world;
+        }
+        if (w.sample_bytes < need_samples) {
+            if (w.samples) HIP_TRY(hipFree(w.samples));
+            w.samples = nullptr; w.sample_bytes = 0;
+            // a device short of memory gets a smaller chunk (more launches), not an error
+            for (;;) {
+                const hipError_t e = hipMalloc((void **)&w.samples, need_samples);
+                if (e == hipSuccess) break;
+                (void)hipGetLastError();
+                w.samples = nullptr;
+                if (e != hipErrorOutOfMemory || chunk <= 1)
+                    return fail(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("rt_render: sample buffer: ") + hipGetErrorString(e));
+                chunk = (chunk + 1) / 2;
+                need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+            }
+            w.sample_bytes = need_samples;
+        } else if (w.sample_bytes < (size_t)bytes_per_sample_row * (size_t)chunk) {
+            chunk = (int64_t)(w.sample_bytes / (size_t)bytes_per_sample_row);
+        }
+        if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
+        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 40 * sizeof(unsigned long long)));
+        ws = w;
+    }
+    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 40 * sizeof(unsigned long long), stream));
+
+    KParams K{};
+    K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
+    K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
+    K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
+    K.out = d_out;
+    K.samples = ws.samples;
+    K.att_stack = ws.att_stack;
+    K.job_counter = ws.job_counter;
+    K.counters = counted ? ws.counters : nullptr;
+    K.cam = *camera;
+    K.seed_mixed = host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
+    K.n_nodes = scene->n_nodes;
+    K.n_threads = n_threads;
+    K.max_depth = p.max_depth;
+    K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
+    K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
+    K.inv_tiles_x = 1.0 / (double)K.tiles_x;
+    K.n_local_tiles = (uint32_t)n_local;
+    K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
+    K.lds_off_node_b = scene->lds_off_node_b;
+    K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
+    K.world_slots = ws.world_slots;
+    K.box_extent = scene->box_extent;
+    K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
+    K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
+    K.aux_image = scene->aux_image.ptr; K.aux_bytes = scene->aux_bytes; K.lds_aux_off = (uint32_t)aux_offset(scene, lds);
+    K.aux_off_mats = scene->aux_off[0]; K.aux_off_texs = scene->aux_off[1]; K.aux_off_insts = scene->aux_off[2];
+    K.aux_off_media = scene->aux_off[3]; K.aux_off_perlins = scene->aux_off[4];
+    K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
+    {
+        const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
+        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : (scene->ordered ? tn.ordered_general : tn.general)));
+        K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
+    }
+
+    const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
+    for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk) {
+        const int64_t ns = (p.sample_end - sb) < chunk ? (p.sample_end - sb) : chunk;
+        K.sample_begin = (int32_t)sb;
+        K.n_samples = (uint32_t)ns;
+        K.n_jobs = (uint32_t)(n_local * 64 * ns);
+        K.inv_n_samples = 1.0 / (double)ns;
+        {
+            // ~32 grabs per wave or more, rounded down to a multiple of 64 within [MIN, MAX]
+            const int64_t waves = grid * waves_per_block;
+            int64_t per_grab = (int64_t)K.n_jobs / (waves * 32);
+            if (tn.jobs_per_grab > 0) per_grab = tn.jobs_per_grab;
+            per_grab = per_grab / 64 * 64;
+            if (per_grab > MAX_JOBS_PER_GRAB) per_grab = MAX_JOBS_PER_GRAB;
+            if (per_grab < MIN_JOBS_PER_GRAB) per_grab = MIN_JOBS_PER_GRAB;
+            K.jobs_per_grab = (uint32_t)per_grab;
+        }
+        K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
+        HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
+        {
+            void *args[] = {(void *)&K};
+            HIP_TRY(hipLaunchKernel(path_kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered, aux_in_lds(scene, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
+        }
+        HIP_TRY(hipGetLastError());
+        launch_sum_samples(K, sum_grid, stream);
+        HIP_TRY(hipGetLastError());
+    }
+
+    if (counted) {
+        unsigned long long host[40];
+        HIP_TRY(hipMemcpyAsync(host, ws.counters, sizeof host, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        {
+            std::lock_guard<std::mutex> lock(g_stage_profile_mu);
+            for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) g_stage_profile[q] = host[10 + q];
+        }
+        out_counters->samples = host[0]; out_counters->rays = host[1]; out_counters->node_visits = host[2];
+        out_counters->sphere_tests = host[3]; out_counters->quad_tests = host[4]; out_counters->medium_visits = host[5];
+        out_counters->rng_draws = host[6]; out_counters->noise_evals = host[7]; out_counters->image_lookups = host[8];
+        out_counters->instance_enters = host[9];
+    }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+const char *rt_version(void) { return "rt_amd 0.1 (gfx950, abi 1)"; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t rt_out_size(int32_t width, int32_t height, int32_t out_layout, int32_t shard_index, int32_t shard_count) {
+    if (width <= 0 || height <= 0) return -1;
+    if (shard_count <= 0) shard_count = 1;
+    if (shard_index < 0 || shard_index >= shard_count) return -1;
+    if (out_layout == RT_OUT_FRAME) return (int64_t)width * height * 3;
+    if (out_layout == RT_OUT_TILES) return tiles_local(width, height, shard_index, shard_count) * RT_TILE_W * RT_TILE_H * 3;
+    return -1;
+}
+
+// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py), own trees vs reference
+// order, Msamples/s: two_spheres 3978 / 4813, earth 15970 / 19317, two_perlin_spheres 2349 / 2651, simple_light 3060 /
+// 3322 (1-4 primitives: a tree and a stack are overhead); quads 15790 / 14393, cornell_box 2206 / 1967, random_balls 3557 /
+// 2038, final_scene 821 / 624; cornell_smoke 496 / 736 (18 quads, and two media whose rotated-box boundaries are walked as
+// trees of their own, twice per visit).
+static bool ordered_walk_pays(const CompiledScene &cs) {
+    const size_t prims = cs.spheres.size() + cs.quads.size();
+    if (prims <= 4) return false;
+    bool general_boundary = false;
+    for (const Node &n : cs.nodes)
+        if ((n.kind & NODE_KIND_MASK) == NK_MEDIUM_ENTER) general_boundary = true;
+    if (general_boundary && prims < 64) return false;
+    return true;
+}
+
+void rt_scene_options_init(rt_scene_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->struct_size = (uint32_t)sizeof *o;
+    o->walk = RT_WALK_DEFAULT; o->leaf_max = 0; o->refit = -1; o->use_lds = -1;
+    o->th_prim = o->th_other = o->th_shade = o->th_box = o->th_new = -1;
+    o->sample_buffer_bytes = 0;
+}
+
+int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) { return rt_scene_create_ex(desc, device, nullptr, out_scene); }
+
+int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_options *options, rt_scene **out_scene) {
+    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
+    *out_scene = nullptr;
+    rt_scene_options opt;
+    rt_scene_options_init(&opt);
+    if (options) {
+        if (options->struct_size < 8 || options->struct_size > sizeof opt) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create_ex: rt_scene_options.struct_size is not one this library knows");
+        memcpy(&opt, options, options->struct_size); // (an older, shorter struct: the fields it lacks keep their defaults)
+        opt.struct_size = (uint32_t)sizeof opt;
+    }
+    if (opt.walk < RT_WALK_DEFAULT || opt.walk > RT_WALK_OWN_TREES) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create_ex: unknown walk");
+    // the process defaults in force now (RT_* variables, rt_debug_set_*), then the caller's options
+    const Tuning tn = tuning_snapshot();
+    const int walk = opt.walk != RT_WALK_DEFAULT ? opt.walk : tn.ordered;
+    const bool refit = opt.refit >= 0 ? opt.refit != 0 : tn.refit != 0;
+    OrderedOptions oopt = tn.ordered_options;
+    if (opt.leaf_max > 0) oopt.leaf_max = (uint32_t)opt.leaf_max < OREF_MAX_LEAF ? (uint32_t)opt.leaf_max : OREF_MAX_LEAF;
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc, refit);
+        if (walk == RT_WALK_OWN_TREES || (walk == RT_WALK_AUTO && ordered_walk_pays(cs))) build_ordered(cs, oopt);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_scene_create: ") + e.what());
+    }
+    const int ndev = rt_device_count();
+    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    rt_scene *s = new rt_scene();
+    s->device = device;
+    s->options = opt;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "hipGetDeviceProperties failed"); }
+    s->n_cus = prop.multiProcessorCount;
+    s->has_instances = !cs.instances.empty();
+    s->features = (cs.spheres.empty() ? 0u : F_SPHERES) | (cs.quads.empty() ? 0u : F_QUADS) | (cs.instances.empty() ? 0u : F_FRAMES) |
+                  (cs.media.empty() ? 0u : F_MEDIA);
+    for (const auto &t : cs.textures)
+        if (t.kind != RT_TEXTURE_SOLID) s->features |= F_TEXTURES;
+    s->ordered = cs.ordered;
+    // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
+    s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
+    s->n_oseq = (uint32_t)cs.oseq.size();
+    for (const ONode &nd : cs.onodes)
+        for (int k = 0; k < 6; ++k) {
+            if ((nd.c[0] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b0[k]));
+            if ((nd.c[1] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b1[k]));
+        }
+    for (const OSeq &st : cs.oseq)
+        for (int k = 0; k < 6; ++k) s->box_extent = std::fmax(s->box_extent, std::fabs(st.box[k]));
+    s->o_stack = cs.ordered_stack;
+    // Node tables (load_node / load_opair): threaded records as two 16-byte halves, ordered records as six 16-byte plane
+    // tables and an 8-byte reference table.  LDS image = node tables | spheres | quads; every LDS level copies a prefix.
+    {
+        const size_t n = cs.ordered ? cs.onodes.size() : cs.nodes32.size();
+        const size_t off_b = n * 16; // bytes of one 16-byte-per-record table
+        const size_t off_sph = cs.ordered ? ((n * (6 * 16 + 8) + 15u) & ~(size_t)15u) : n * 32;
+        std::vector<uint4> tables(off_sph / 16);
+        {
+            unsigned char *base = reinterpret_cast<unsigned char *>(tables.data());
+            if (cs.ordered) {
+                for (size_t i = 0; i < n; ++i) {
+                    const ONode &nd = cs.onodes[i];
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const float lo0 = nd.b0[2 * ax], hi0 = nd.b0[2 * ax + 1], lo1 = nd.b1[2 * ax], hi1 = nd.b1[2 * ax + 1];
+                        const float plus[4] = {lo0, lo1, hi0, hi1}, minus[4] = {hi0, hi1, lo0, lo1};
+                        memcpy(base + (size_t)(2 * ax) * off_b + i * 16, plus, 16);
+                        memcpy(base + (size_t)(2 * ax + 1) * off_b + i * 16, minus, 16);
+                    }
+                    memcpy(base + 6 * off_b + i * 8, nd.c, 8);
+                }
+            } else {
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(cs.nodes32.data());
+                for (size_t i = 0; i < n; ++i)
+                    for (size_t q = 0; q < 2; ++q) memcpy(base + q * off_b + i * 16, src + (i * 2 + q) * 16, 16);
+            }
+        }
+        if (cs.ordered) { // the global copy: one 128-byte line per record (load_opair<0>)
+            std::vector<uint4> lines(n * 8);
+            unsigned char *dst = reinterpret_cast<unsigned char *>(lines.data());
+            const unsigned char *tab = reinterpret_cast<const unsigned char *>(tables.data());
+            for (size_t i = 0; i < n; ++i) {
+                for (size_t q = 0; q < 6; ++q) memcpy(dst + i * 128 + q * 16, tab + q * off_b + i * 16, 16);
+                memcpy(dst + i * 128 + 96, tab + 6 * off_b + i * 8, 8);
+            }
+            int urc = upload(s->oimage, lines);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+        }
+        s->lds_off_node_b = (uint32_t)off_b;
+        const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
+        const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
+        const size_t stack = stack_bytes(s, 1);
+        // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
+        // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
+        const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
+        s->lds_level = total + stack <= budget ? 3 : (off_sph + stack <= budget ? 1 : 0);
+        if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits
+        if (s->lds_level) {
+            const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
+            std::vector<uint4> img(used / 16);
+            unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
+            memcpy(base, tables.data(), off_sph);
+            if (s->lds_level >= 2 && !cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
+            if (s->lds_level == 3 && !cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
+            int urc = upload(s->lds_image, img);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+            s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;
+            s->lds_image_bytes = (uint32_t)used;
+            s->lds_prefix_bytes[1] = (uint32_t)off_sph;
+            s->lds_prefix_bytes[2] = (uint32_t)((off_quads + 15u) & ~(size_t)15u);
+            s->lds_prefix_bytes[3] = (uint32_t)total;
+            for (int l = s->lds_level + 1; l < 4; ++l) s->lds_prefix_bytes[l] = 0;
+        }
+    }
+    std::vector<DMaterial> mats(cs.materials.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const rt_material &m = cs.materials[i];
+        DMaterial d{};
+        d.kind = (uint32_t)m.kind;
+        d.texture = m.texture >= 0 ? (uint32_t)m.texture : 0u;
+        d.needs_uv = texture_needs_uv(cs.textures, m.texture) ? 1u : 0u;
+        d.albedo[0] = m.albedo.x; d.albedo[1] = m.albedo.y; d.albedo[2] = m.albedo.z;
+        if (m.kind != RT_MATERIAL_METAL && m.kind != RT_MATERIAL_DIELECTRIC && m.texture >= 0 &&
+            cs.textures[(size_t)m.texture].kind == RT_TEXTURE_SOLID) {
+            const rt_vec3 &c = cs.textures[(size_t)m.texture].color;
+            d.solid = 1u;
+            d.albedo[0] = c.x; d.albedo[1] = c.y; d.albedo[2] = c.z;
+        }
+        d.fuzz = m.fuzz;
+        d.ir = m.ir;
+        mats[i] = d;
+    }
+
+    // AUX image (path_kernel's AUX): the small tables, for ordered scenes whose big tables stay in global memory
+    {
+        auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
+        const size_t o_mats = 0, o_texs = align16(o_mats + mats.size() * sizeof(DMaterial)),
+                     o_insts = align16(o_texs + cs.textures.size() * sizeof(rt_texture)),
+                     o_media = align16(o_insts + cs.instances.size() * sizeof(Instance)),
+                     o_perlins = align16(o_media + cs.media.size() * sizeof(Medium)),
+                     total = align16(o_perlins + cs.perlins.size() * sizeof(rt_perlin));
+        if (s->ordered && s->lds_level == 0 && total > 0 && total <= 24 * 1024) {
+            std::vector<uint4> img(total / 16);
+            unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
+            if (!mats.empty()) memcpy(base + o_mats, mats.data(), mats.size() * sizeof(DMaterial));
+            if (!cs.textures.empty()) memcpy(base + o_texs, cs.textures.data(), cs.textures.size() * sizeof(rt_texture));
+            if (!cs.instances.empty()) memcpy(base + o_insts, cs.instances.data(), cs.instances.size() * sizeof(Instance));
+            if (!cs.media.empty()) memcpy(base + o_media, cs.media.data(), cs.media.size() * sizeof(Medium));
+            if (!cs.perlins.empty()) memcpy(base + o_perlins, cs.perlins.data(), cs.perlins.size() * sizeof(rt_perlin));
+            int urc = upload(s->aux_image, img);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+            s->aux_bytes = (uint32_t)total;
+            s->aux_off[0] = (uint32_t)o_mats; s->aux_off[1] = (uint32_t)o_texs; s->aux_off[2] = (uint32_t)o_insts;
+            s->aux_off[3] = (uint32_t)o_media; s->aux_off[4] = (uint32_t)o_perlins;
+        }
+    }
+    for (int lds = 0; lds < 4; ++lds)
+        for (int counted = 0; counted < 2; ++counted) {
+            if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
+            const void *fn = path_kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered, aux_in_lds(s, lds));
+            const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+            const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            int b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
+            s->blocks_per_cu[lds][counted] = b;
+        }
+
+    int rc = RT_OK;
+    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->oseq, cs.oseq)) != RT_OK ||
+        (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
+        (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
+        (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
+        (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
+        (rc = upload(s->images, cs.images)) != RT_OK || (rc = upload(s->texels, cs.texels)) != RT_OK ||
+        (rc = upload(s->lut, cs.srgb_lut)) != RT_OK) {
+        free_scene(s);
+        return rc;
+    }
+    s->n_nodes = (uint32_t)cs.nodes.size();
+    rt_scene_stats &st = s->stats;
+    st.node_bytes = cs.ordered ? s->oimage.bytes : s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
+    st.instance_bytes = s->insts.bytes; st.medium_bytes = s->media.bytes; st.material_bytes = s->mats.bytes;
+    st.texture_bytes = s->texs.bytes; st.perlin_bytes = s->perlins.bytes; st.image_bytes = s->texels.bytes;
+    st.n_nodes = (uint32_t)(cs.ordered ? cs.onodes.size() : cs.nodes.size()); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
+    st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
+    st.max_instance_depth = cs.max_instance_depth;
+    st.lds_nodes = s->lds_level ? st.n_nodes : 0; st.lds_bytes = s->lds_level ? (uint32_t)dynamic_lds_bytes(s, s->lds_level, false) : 0;
+    st.ordered = cs.ordered ? 1u : 0u; st.stack_entries = cs.ordered ? cs.ordered_stack : 0u;
+    *out_scene = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *scene) { free_scene(scene); }
+
+int rt_scene_get_stats(const rt_scene *scene, rt_scene_stats *out) {
+    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_get_stats: null argument");
+    *out = scene->stats;
+    return RT_OK;
+}
+
+int rt_render_device(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params, double *d_out_rgb_sum,
+                     void *hip_stream) {
+    if (!scene || !camera || !params || !d_out_rgb_sum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null argument");
+    return launch_render(const_cast<rt_scene *>(scene), camera, *params, d_out_rgb_sum, (hipStream_t)hip_stream, nullptr);
+}
+
+int rt_render_device_counted(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
+                             double *d_out_rgb_sum, void *hip_stream, rt_counters *out_counters) {
+    if (!scene || !camera || !params || !d_out_rgb_sum || !out_counters)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_counted: null argument");
+    return launch_render(const_cast<rt_scene *>(scene), camera, *params, d_out_rgb_sum, (hipStream_t)hip_stream, out_counters);
+}
+
+int rt_render(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params, double *out_rgb_sum) {
+    if (!scene || !camera || !params || !out_rgb_sum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
+    rt_render_params p = *params;
+    int rc = normalise_params(camera, p);
+    if (rc != RT_OK) return rc;
+    rt_scene *s = const_cast<rt_scene *>(scene);
+    std::lock_guard<std::mutex> serial(s->host_render_mu);
+    HIP_TRY(hipSetDevice(s->device));
+    const int32_t w = camera->image_width, h = camera->image_height;
+    // on the device the shard always renders into its compact tile buffer; the requested layout is produced on the host
+    rt_render_params dp = p;
+    dp.out_layout = RT_OUT_TILES;
+    const int64_t n_tiles_vals = rt_out_size(w, h, RT_OUT_TILES, p.shard_index, p.shard_count);
+    if (n_tiles_vals <= 0) return RT_OK;
+    const int32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
+    const int64_t n_local = n_tiles_vals / (RT_TILE_W * RT_TILE_H * 3);
+    std::vector<double> tiles((size_t)n_tiles_vals);
+    auto for_each_pixel = [&](auto &&fn) {
+        for (int64_t lt = 0; lt < n_local; ++lt) {
+            const int64_t k = lt * p.shard_count + p.shard_index;
+            const int32_t x0 = (int32_t)(k % tiles_x) * RT_TILE_W, y0 = (int32_t)(k / tiles_x) * RT_TILE_H;
+            for (int32_t ty = 0; ty < RT_TILE_H; ++ty)
+                for (int32_t tx = 0; tx < RT_TILE_W; ++tx) {
+                    const int32_t i = x0 + tx, j = y0 + ty;
+                    if (i >= w || j >= h) continue;
+                    fn(&tiles[(size_t)((lt * RT_TILE_H + ty) * RT_TILE_W + tx) * 3u], ((size_t)j * w + i) * 3u);
+                }
+        }
+    };
+    if (p.accumulate) { // seed the device buffer with the caller's running sums
+        if (p.out_layout == RT_OUT_TILES) std::copy(out_rgb_sum, out_rgb_sum + n_tiles_vals, tiles.begin());
+        else for_each_pixel([&](double *t, size_t f) { t[0] = out_rgb_sum[f]; t[1] = out_rgb_sum[f + 1]; t[2] = out_rgb_sum[f + 2]; });
+    }
+    double *d_tiles = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_tiles, (size_t)n_tiles_vals * sizeof(double)));
+    hipStream_t stream = nullptr;
+    rc = RT_OK;
+    do {
+        if (p.accumulate && hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_render: upload of running sums failed");
+            break;
+        }
+        rc = launch_render(s, camera, dp, d_tiles, stream, nullptr);
+        if (rc != RT_OK) break;
+        hipError_t e = hipMemcpy(tiles.data(), d_tiles, tiles.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(RT_ERR_HIP, std::string("rt_render: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    (void)hipFree(d_tiles);
+    if (rc != RT_OK) return rc;
+    if (p.out_layout == RT_OUT_TILES) std::copy(tiles.begin(), tiles.end(), out_rgb_sum);
+    else for_each_pixel([&](double *t, size_t f) { out_rgb_sum[f] = t[0]; out_rgb_sum[f + 1] = t[1]; out_rgb_sum[f + 2] = t[2]; });
+    return RT_OK;
+}
+
+int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count, const double *d_gathered, double *d_frame,
+                             void *hip_stream) {
+    if (!d_gathered || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_tiles_to_frame_device: bad argument");
+    const int64_t stride = rt_out_size(width, height, RT_OUT_TILES, 0, shard_count);
+    const int32_t tiles_x = (width + RT_TILE_W - 1) / RT_TILE_W;
+    launch_tiles_to_frame(width, height, tiles_x, shard_count, stride, d_gathered, d_frame, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+int rt_tiles_to_frame_rgb8_device(int32_t width, int32_t height, int32_t shard_count, const uint8_t *d_gathered, uint8_t *d_frame,
+                                  void *hip_stream) {
+    if (!d_gathered || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_tiles_to_frame_rgb8_device: bad argument");
+    const int64_t stride = rt_out_size(width, height, RT_OUT_TILES, 0, shard_count);
+    const int32_t tiles_x = (width + RT_TILE_W - 1) / RT_TILE_W;
+    launch_tiles_to_frame_rgb8(width, height, tiles_x, shard_count, stride, d_gathered, d_frame, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_resolve_rgb8_values_device(int64_t n_values, int32_t spp, const double *d_sum, uint8_t *d_rgb8, void *hip_stream) {
+    if (!d_sum || !d_rgb8 || n_values <= 0 || spp <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_resolve_rgb8_values_device: bad argument");
+    launch_resolve_rgb8(n_values, 1.0 / (double)spp, d_sum, d_rgb8, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_resolve_rgb8_device(int32_t width, int32_t height, int32_t spp, const double *d_frame_sum, uint8_t *d_rgb8, void *hip_stream) {
+    if (width <= 0 || height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_resolve_rgb8_device: bad argument");
+    return rt_resolve_rgb8_values_device((int64_t)width * height * 3, spp, d_frame_sum, d_rgb8, hip_stream);
+}
+
+} // extern "C"

@@ -1,0 +1,124 @@
+// rt_api.hpp — internals shared by the host-side translation units of librt_amd (rt_api.cpp, rt_debug.cpp, rt_gather.cpp).
+#pragma once
+#include "rt_amd.h"
+#include "rt_amd_debug.h"
+#include "rt_compile.hpp"
+#include "rt_kernels.h"
+#include "rt_ordered.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace rtapi {
+using namespace rtd;
+using namespace rtk;
+
+int fail(int status, const std::string &msg); // sets rt_last_error() of the calling thread, returns `status`
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            return rtapi::fail(_e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                  \
+                               std::string(#expr) + ": " + hipGetErrorString(_e));                             \
+    } while (0)
+
+struct Workspace {
+    double *att_stack = nullptr;
+    size_t att_bytes = 0;
+    double *world_slots = nullptr; // [6][n_threads]
+    size_t world_bytes = 0;
+    double *samples = nullptr; // sample buffer of one launch
+    size_t sample_bytes = 0;
+    uint32_t *job_counter = nullptr;
+    unsigned long long *counters = nullptr;
+};
+
+// Scheduler knobs (64ths of the live lanes a deferred stage must have queued / the box loop needs to keep running).
+// The best values depend on the stage mix, so there is one preset per kernel instantiation, each picked with
+// tools/tune.py on MI355X (DESIGN.md "Scheduler"); a value >= 0 in `forced` (RT_TH_* variables, rt_debug_set_tuning)
+// overrides all presets.
+struct Thresholds { uint32_t prim, other, shade, box, newjob; };
+struct Tuning {
+    Thresholds general{8, 8, 48, 8, 0};
+    Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
+    Thresholds spheres_solid{8, 16, 24, 16, 32}; // random-spheres
+    Thresholds quads_frames{8, 16, 40, 4, 8};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
+    int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
+    int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
+    int refit = 1;   // 0: walk the reference's own (looser) boxes
+    int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
+                     // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
+    int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
+    OrderedOptions ordered_options;
+    size_t sample_buffer_bytes = (size_t)2 << 30; // per-(scene, stream) sample buffer at most (halved on out-of-memory)
+    Tuning();
+    Thresholds pick(const Thresholds &preset) const {
+        Thresholds t = preset;
+        if (forced[0] >= 0) t.prim = (uint32_t)forced[0];
+        if (forced[1] >= 0) t.other = (uint32_t)forced[1];
+        if (forced[2] >= 0) t.shade = (uint32_t)forced[2];
+        if (forced[3] >= 0) t.box = (uint32_t)forced[3];
+        if (forced[4] >= 0) t.newjob = (uint32_t)forced[4];
+        return t;
+    }
+};
+// Process-wide defaults (RT_* environment variables, rt_debug_set_*): read and written under one mutex; a scene takes its
+// copy when it is created (walk, refit, tree options) and every launch takes one (thresholds, LDS use).
+Tuning tuning_snapshot();
+void tuning_update(void (*fn)(Tuning &, const void *), const void *arg);
+
+template <class T> struct DeviceArray {
+    T *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace rtapi
+
+using namespace rtapi; // (an internal header of three translation units)
+
+struct rt_scene {
+    int device = 0;
+    int n_cus = 0;
+    int blocks_per_cu[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; // [LDS level][counted?]
+    rtapi::DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
+    uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
+    bool has_instances = false;
+    int lds_level = 0;                          // 0 nothing fits, 1 nodes, 2 nodes + spheres, 3 nodes + spheres + quads
+    uint32_t features = F_ALL;                  // Feature bits the scene uses
+    uint32_t lds_prefix_bytes[4] = {0, 0, 0, 0}; // image prefix each LDS level copies in
+    rtapi::DeviceArray<Node32> nodes;
+    rtapi::DeviceArray<Sphere> spheres;
+    rtapi::DeviceArray<Quad> quads;
+    rtapi::DeviceArray<Instance> insts;
+    rtapi::DeviceArray<Medium> media;
+    rtapi::DeviceArray<DMaterial> mats;
+    rtapi::DeviceArray<rt_texture> texs;
+    rtapi::DeviceArray<rt_perlin> perlins;
+    rtapi::DeviceArray<ImageRef> images;
+    rtapi::DeviceArray<uint8_t> texels;
+    rtapi::DeviceArray<double> lut;
+    uint32_t n_nodes = 0;
+    bool ordered = false;                        // ordered layout (rt_ordered.hpp): onodes instead of nodes
+    rtapi::DeviceArray<uint4> oimage;                   // ordered layout: the tables of load_opair (global copy)
+    rtapi::DeviceArray<OSeq> oseq;                      // ... and the world frame's sequence
+    uint32_t n_oseq = 0;
+    float box_extent = 0.0f;                     // largest |coordinate| of any box of the ordered layout
+    rtapi::DeviceArray<uint4> aux_image;                // materials | textures | frames | media | Perlin for the AUX kernels (0 bytes: not used)
+    uint32_t aux_bytes = 0, aux_off[5] = {0, 0, 0, 0, 0};
+    uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
+    rt_scene_stats stats{};
+    std::mutex mu;
+    std::map<hipStream_t, rtapi::Workspace> workspaces; // one per stream: launches on a stream are ordered
+    rt_scene_options options;                    // the caller's per-scene options (rt_scene_create_ex); unset fields: process defaults
+    std::mutex host_render_mu;                   // rt_render (host-buffer form) calls on one scene run one at a time
+};
+
+namespace rtapi {
+// of the last counted render: per profile slot (rounds, active lanes, cycles)
+extern std::mutex g_stage_profile_mu;
+extern unsigned long long g_stage_profile[PROF_SLOTS * 3];
+} // namespace rtapi

@@ -1,0 +1,195 @@
+// rt_debug.cpp — the test and tuning hooks of include/rt_amd_debug.h (not part of the drop-in boundary).
+#include "rt_api.hpp"
+
+#include <cmath>
+#include <cstring>
+
+using namespace rtapi;
+
+extern "C" {
+
+int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds, int32_t th_new) {
+    const int32_t v[6] = {th_prim, th_other, th_shade, th_box, th_new, use_lds};
+    tuning_update([](Tuning &t, const void *arg) {
+        const int32_t *a = static_cast<const int32_t *>(arg);
+        for (int k = 0; k < 5; ++k) t.forced[k] = a[k];
+        if (a[5] >= 0) t.use_lds = a[5];
+    }, v);
+    return RT_OK;
+}
+
+int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max) {
+    const int32_t v[2] = {ordered, leaf_max};
+    tuning_update([](Tuning &t, const void *arg) {
+        const int32_t *a = static_cast<const int32_t *>(arg);
+        if (a[0] >= 0) t.ordered = a[0];
+        if (a[1] > 0) t.ordered_options.leaf_max = (uint32_t)a[1] < OREF_MAX_LEAF ? (uint32_t)a[1] : OREF_MAX_LEAF;
+        else if (a[1] == 0) t.ordered_options.leaf_max = OrderedOptions().leaf_max;
+    }, v);
+    return RT_OK;
+}
+
+int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) {
+    if (!desc || !io) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: null argument");
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc, true);
+        build_ordered(cs, tuning_snapshot().ordered_options);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_ordered_layout: ") + e.what());
+    }
+    io->ordered = cs.ordered ? 1u : 0u;
+    io->root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0u;
+    io->n_steps = (int64_t)cs.oseq.size();
+    if (io->steps) {
+        if (io->cap_steps < io->n_steps) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: steps buffer too small");
+        if (io->n_steps) memcpy(io->steps, cs.oseq.data(), cs.oseq.size() * sizeof(OSeq));
+    }
+    io->n_media = (int64_t)cs.media.size();
+    if (io->media) {
+        if (io->cap_media < io->n_media) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: media buffer too small");
+        for (size_t i = 0; i < cs.media.size(); ++i) io->media[i] = cs.media[i].first_node;
+    }
+    io->stack_entries = cs.ordered_stack;
+    io->n_nodes = (int64_t)cs.onodes.size(); io->n_spheres = (int64_t)cs.spheres.size();
+    io->n_quads = (int64_t)cs.quads.size(); io->n_instances = (int64_t)cs.instances.size();
+    if (io->nodes) {
+        if (io->cap_nodes < io->n_nodes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: nodes buffer too small");
+        if (io->n_nodes) memcpy(io->nodes, cs.onodes.data(), cs.onodes.size() * sizeof(ONode));
+    }
+    if (io->spheres) {
+        if (io->cap_spheres < io->n_spheres) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: spheres buffer too small");
+        for (size_t i = 0; i < cs.spheres.size(); ++i) {
+            const Sphere &sp = cs.spheres[i];
+            double *o = io->spheres + i * 9;
+            for (int k = 0; k < 3; ++k) { o[k] = sp.center[k]; o[4 + k] = sp.center_vec[k]; }
+            o[3] = sp.radius; o[7] = (double)(sp.seq_moving >> 1); o[8] = (double)(sp.seq_moving & 1u);
+        }
+    }
+    if (io->quads) {
+        if (io->cap_quads < io->n_quads) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: quads buffer too small");
+        for (size_t i = 0; i < cs.quads.size(); ++i) {
+            const Quad &qd = cs.quads[i];
+            double *o = io->quads + i * 10;
+            for (int k = 0; k < 3; ++k) { o[k] = qd.q[k]; o[3 + k] = qd.u[k]; o[6 + k] = qd.v[k]; }
+            o[9] = (double)qd.seq;
+        }
+    }
+    if (io->instances) {
+        if (io->cap_instances < io->n_instances) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: instances buffer too small");
+        for (size_t i = 0; i < cs.instances.size(); ++i) {
+            const Instance &in = cs.instances[i];
+            double *o = io->instances + i * 8;
+            for (int k = 0; k < 3; ++k) o[k] = in.offset[k];
+            o[3] = in.sin_theta; o[4] = in.cos_theta; o[5] = (double)in.parent; o[6] = (double)in.flags; o[7] = (double)in.root;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity, int64_t *out_count) {
+    if (!desc || !out_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: null argument");
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc, refit != 0);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_compiled_nodes: ") + e.what());
+    }
+    *out_count = (int64_t)cs.nodes.size();
+    if (!out_nodes) return RT_OK;
+    if ((int64_t)cs.nodes.size() > capacity) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: buffer too small");
+    for (size_t i = 0; i < cs.nodes.size(); ++i) {
+        const Node &n = cs.nodes[i];
+        const Node32 &m = cs.nodes32[i];
+        rt_debug_node &o = out_nodes[i];
+        for (int k = 0; k < 3; ++k) { o.lo[k] = n.lo[k]; o.hi[k] = n.hi[k]; }
+        o.lo32[0] = m.bx[0]; o.hi32[0] = m.bx[1]; o.lo32[1] = m.by[0]; o.hi32[1] = m.by[1]; o.lo32[2] = m.bz[0]; o.hi32[2] = m.bz[1];
+        o.skip = n.skip; o.kind = n.kind & NODE_KIND_MASK; o.no_bbox = (n.kind & NODE_NO_BBOX) ? 1u : 0u; o.a = n.a; o.b = n.b;
+        o.prim_lo[0] = o.prim_lo[1] = o.prim_lo[2] = INFINITY;
+        o.prim_hi[0] = o.prim_hi[1] = o.prim_hi[2] = -INFINITY;
+        // bound of the record's own primitives (leaves), in the frame the record lives in
+        auto grow = [&](double x, double y, double z) {
+            const double p[3] = {x, y, z};
+            for (int k = 0; k < 3; ++k) { o.prim_lo[k] = std::fmin(o.prim_lo[k], p[k]); o.prim_hi[k] = std::fmax(o.prim_hi[k], p[k]); }
+        };
+        if (o.kind == NK_SPHERES || o.kind == NK_MEDIUM_SPHERE) {
+            const uint32_t first = o.kind == NK_SPHERES ? n.a : cs.media[n.a].first_node, count = o.kind == NK_SPHERES ? n.b : 1u;
+            for (uint32_t q = first; q < first + count; ++q) {
+                const Sphere &sp = cs.spheres[q];
+                for (int e = 0; e < ((sp.seq_moving & 1u) ? 2 : 1); ++e) {
+                    const double c[3] = {sp.center[0] + e * sp.center_vec[0], sp.center[1] + e * sp.center_vec[1], sp.center[2] + e * sp.center_vec[2]};
+                    grow(c[0] - sp.radius, c[1] - sp.radius, c[2] - sp.radius);
+                    grow(c[0] + sp.radius, c[1] + sp.radius, c[2] + sp.radius);
+                }
+            }
+        } else if (o.kind == NK_QUADS) {
+            for (uint32_t q = n.a; q < n.a + n.b; ++q) {
+                const Quad &qd = cs.quads[q];
+                for (int i2 = 0; i2 < 2; ++i2)
+                    for (int j2 = 0; j2 < 2; ++j2)
+                        grow(qd.q[0] + i2 * qd.u[0] + j2 * qd.v[0], qd.q[1] + i2 * qd.u[1] + j2 * qd.v[1], qd.q[2] + i2 * qd.u[2] + j2 * qd.v[2]);
+            }
+        }
+    }
+    return RT_OK;
+}
+
+int rt_debug_stage_profile(uint64_t out[24]) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
+    std::lock_guard<std::mutex> lock(g_stage_profile_mu);
+    for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) out[q] = g_stage_profile[q];
+    return RT_OK;
+}
+
+int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *out_exact_hit,
+                       uint8_t *out_f32_hit, int device) {
+    if (n <= 0 || !rays || !boxes || !out_exact_hit || !out_f32_hit) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_box_tests: bad argument");
+    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_box_tests: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *dr = nullptr, *db = nullptr;
+    uint8_t *de = nullptr, *df = nullptr;
+    const size_t bytes = (size_t)n * 6 * sizeof(double);
+    int rc = RT_OK;
+    do {
+        if (hipMalloc((void **)&dr, bytes) != hipSuccess || hipMalloc((void **)&db, bytes) != hipSuccess ||
+            hipMalloc((void **)&de, (size_t)n) != hipSuccess || hipMalloc((void **)&df, (size_t)n) != hipSuccess) {
+            rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_box_tests: hipMalloc failed"); break;
+        }
+        if (hipMemcpy(dr, rays, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, boxes, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_debug_box_tests: upload failed"); break;
+        }
+        launch_debug_box(n, dr, db, tmin, tmax, de, df);
+        if (hipMemcpy(out_exact_hit, de, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_f32_hit, df, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_debug_box_tests: download failed"); break;
+        }
+    } while (0);
+    (void)hipFree(dr); (void)hipFree(db); (void)hipFree(de); (void)hipFree(df);
+    return rc;
+}
+
+int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device) {
+    if (n <= 0 || !a || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_eval: bad argument");
+    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_eval: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    int rc = RT_OK;
+    do {
+        if (hipMalloc((void **)&da, bytes) != hipSuccess || hipMalloc((void **)&dout, bytes) != hipSuccess ||
+            (b && hipMalloc((void **)&db, bytes) != hipSuccess)) { rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_eval: hipMalloc failed"); break; }
+        if (hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            (b && hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) != hipSuccess)) { rc = fail(RT_ERR_HIP, "rt_debug_eval: upload failed"); break; }
+        launch_debug_eval(op, n, da, db, dout);
+        hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(RT_ERR_HIP, std::string("rt_debug_eval: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+}
+
+} // extern "C"

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rt_shared_math.h"
+
 namespace rtk {
 
 #define RT_DEV __device__ __forceinline__
@@ -50,14 +52,23 @@ RT_DEV uint64_t mix64(uint64_t z) {
 }
 constexpr uint64_t RNG_GAMMA = 0x9E3779B97F4A7C15ull;
 
+// The stream of one camera path: RomuDuoJr (Overton 2020: two 64-bit words, one multiply, one subtract, one rotate per
+// draw — 9 VALU instructions against splitmix64's 20), started from the path's key.
 struct Rng {
-    uint64_t state;
+    uint64_t x, y;
+    RT_DEV void start_key(uint64_t key) {
+        x = key;
+        y = mix64(key + RNG_GAMMA);
+    }
     RT_DEV void start(uint64_t seed_mixed, uint32_t pixel, uint32_t sample) {
-        state = mix64(seed_mixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
+        start_key(mix64(seed_mixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample)));
     }
     RT_DEV uint64_t next() {
-        state += RNG_GAMMA;
-        return mix64(state);
+        const uint64_t xp = x;
+        x = 0xD3833E804F4C574Bull * y;
+        y = y - xp;
+        y = (y << 27) | (y >> 37);
+        return xp;
     }
     RT_DEV double random() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
     RT_DEV double range(double lo, double hi) {
@@ -67,37 +78,8 @@ struct Rng {
 };
 
 // ---- fixed transcendental algorithms (DESIGN.md "Device math") ------------------------------------------
-RT_DEV double rt_log(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
-                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    uint64_t b = f2u(x);
-    if ((b << 1) == 0) return -__builtin_inf();
-    if (b >> 63) return __builtin_nan("");
-    if ((b >> 52) == 0x7ff) return x;
-    int64_t e = (int64_t)(b >> 52);
-    if (e == 0) {
-        x *= 18014398509481984.0;
-        b = f2u(x);
-        e = (int64_t)(b >> 52) - 54;
-    }
-    uint64_t mant = b & 0x000fffffffffffffull;
-    int64_t k;
-    double m;
-    if (mant >= 0x6a09e667f3bcdull) { m = u2f(mant | 0x3fe0000000000000ull); k = e - 1022; }
-    else                            { m = u2f(mant | 0x3ff0000000000000ull); k = e - 1023; }
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double w = z * z;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
-    double R = t2 + t1;
-    double hfsq = 0.5 * f * f;
-    double dk = (double)k;
-    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
-}
+// (ln lives in rt_shared_math.h: the host library's output stage runs the same code)
+using rtm::rt_log;
 
 RT_DEV double k_sin(double x, double y) {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,

@@ -1,29 +1,21 @@
-// rt_kernel.hip — the render megakernel for MI355X (gfx950) and the C ABI of include/rt_amd.h.
+// rt_kernel.hip — the device code of librt_amd for MI355X (gfx950): the render megakernel and the small frame-end kernels.
 //
-// One wavefront owns one 8x8 pixel tile at a time (lane = pixel); waves pull tiles from a device-side
-// counter until none are left, so the grid is sized to the machine, not to the image.  Per pixel and sample
-// a lane generates the camera ray (src/camera.rs:112-137), walks the threaded scene layout (rt_layout.h) —
-// box test, sphere / quad intersection, frame changes, constant media — shades the closest hit with the
-// reference's five materials and four textures (src/material.rs, src/texture.rs), and loops over bounces
-// (ray_color, src/renderer.rs:139-155, made iterative).  All arithmetic is f64 in the reference's operation
-// order with no FMA contraction, so the per-pixel sums equal the CPU restatement's bit for bit.
+// path_kernel is a persistent, wave-scheduled stage machine.  A work unit ("job") is one camera path = (pixel, sample);
+// lanes are not tied to pixels: every wave pulls job ranges from a device-side counter and a lane that finishes a path takes
+// the next job, so the grid is sized to the machine, not to the image.  Per path a lane generates the camera ray
+// (src/camera.rs:112-137), walks the scene — the library's own SAH trees nearest child first (rt_ordered.hpp) or the
+// threaded records in the reference's order (rt_layout.h): box test, sphere / quad intersection, frame changes, constant
+// media — shades the closest hit with the reference's five materials and four textures (src/material.rs, src/texture.rs)
+// and loops over bounces (ray_color, src/renderer.rs:139-155, made iterative).  All arithmetic that reaches a result is f64
+// in the reference's operation order with no FMA contraction, so the per-pixel sums equal the CPU restatement's bit for bit.
 //
-// There is no dense contraction anywhere on this path: no MFMA.  The bound is FP64 VALU issue under
-// divergence plus scene-data gathers (DESIGN.md "Roofline").
-#include "rt_amd.h"
-#include "rt_compile.hpp"
-#include "rt_ordered.hpp"
+// There is no dense contraction anywhere on this path: no MFMA.  The bound is VALU issue under divergence (DESIGN.md
+// "Roofline").  Host side: rt_api.cpp (C ABI, scene upload, launches), rt_debug.cpp (test hooks), rt_gather.cpp (RCCL).
+#include "rt_kernels.h"
+#include "rt_amd_debug.h"
 #include "rt_device_math.h"
-#include "rt_layout.h"
 
 #include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
 
 using namespace rtd;
 using namespace rtk;
@@ -32,68 +24,6 @@ using namespace rtk;
 // Device side
 // =====================================================================================================
 namespace {
-
-struct DMaterial { // 64 bytes
-    uint32_t kind;
-    uint32_t texture;
-    uint32_t needs_uv; // the texture below reads (u, v): only ImageTexture does (src/texture.rs:83)
-    uint32_t solid;    // the texture is a SolidColor: its colour is copied into `albedo` (one dependent load fewer per hit)
-    double albedo[3];  // Metal's albedo, or the SolidColor's colour
-    double fuzz;
-    double ir;
-    double _pad2;
-};
-static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
-
-struct KParams {
-    const Node32 *nodes;
-    const Sphere *spheres;
-    const Quad *quads;
-    const Instance *insts;
-    const Medium *media;
-    const DMaterial *mats;
-    const rt_texture *texs;
-    const rt_perlin *perlins;
-    const ImageRef *images;
-    const uint8_t *texels;
-    const double *srgb_lut;
-    double *out;
-    double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
-    double *att_stack;              // [max_depth + 1][n_threads][3]: attenuations of the current path
-    uint32_t *job_counter;
-    unsigned long long *counters;   // rt_counters as 10 u64, then per profile slot (9): rounds, active lanes, cycles; or null
-    rt_camera cam;
-    uint64_t seed_mixed;            // mix64(seed + gamma)
-    uint32_t n_nodes;
-    uint32_t n_threads;
-    int32_t sample_begin;           // first sample of this launch
-    uint32_t n_samples;             // samples per pixel in this launch
-    uint32_t n_jobs;                // n_local_tiles * n_samples * 64
-    uint32_t jobs_per_grab;
-    double inv_n_samples, inv_tiles_x; // 1 / n_samples, 1 / tiles_x (job decode)
-    int32_t max_depth, accumulate;
-    int32_t shard_index, shard_count, out_layout;
-    int32_t tiles_x;
-    uint32_t n_local_tiles;
-    uint32_t th_prim, th_other, th_shade, th_new; // scheduler thresholds, in 64ths of the live lanes
-    uint32_t th_box;                // the box loop keeps running while this many 64ths of the live lanes are in it
-    // LDS-resident scene (SCENE_IN_LDS kernels): image to copy in, and where its parts start (bytes)
-    const uint4 *lds_image;
-    uint32_t lds_image_bytes;
-    uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
-    double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
-    // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
-    const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
-    const OSeq *oseq;               // the world frame's sequence of trees and media (rt_layout.h)
-    float box_extent;               // the largest |coordinate| of any box of the ordered layout (box_pair_f32's B)
-    const uint4 *aux_image;         // AUX kernels: materials | textures | frames | media | Perlin tables, to copy into the LDS
-    uint32_t aux_bytes, lds_aux_off, aux_off_mats, aux_off_texs, aux_off_insts, aux_off_media, aux_off_perlins;
-    uint32_t n_oseq;
-    uint32_t o_root;
-    uint32_t lds_stack_off;
-    uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)
-    uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
-};
 
 struct Counts {
     uint32_t samples, rays, node_visits, sphere_tests, quad_tests, medium_visits, rng_draws, noise_evals,
@@ -249,12 +179,6 @@ enum Terminal : uint32_t { TERM_BACKGROUND = 0, TERM_ONE = 1, TERM_ZERO = 2, TER
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for (tools/tune.py: 3 beats 2 and 4)
 #endif
-
-constexpr uint32_t PROF_SLOTS = 8;       // COUNT kernels: profile slots per wave (6 stages + 2 parts of the shade stage)
-// Jobs a wave reserves at a time: a multiple of 64 (one sample-row of an 8x8 tile, so the lanes a wave starts together
-// trace neighbouring pixels).  Large grabs mean few atomics; small ones a short tail (the last grab of the slowest wave
-// is all that is left running at the end): launch_render picks the size so that every wave gets at least ~32 grabs.
-constexpr uint32_t MAX_JOBS_PER_GRAB = 1024, MIN_JOBS_PER_GRAB = 64;
 
 // What one box-stage round needs of a record
 struct NodeData {
@@ -464,17 +388,6 @@ RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, dou
     return false;
 }
 
-// What a scene can contain.  A kernel instantiated without a feature has that code compiled out, which matters for
-// more than its size: the register allocation of the whole kernel is set by its hungriest path.
-enum Feature : uint32_t {
-    F_SPHERES = 1u,  // Sphere leaves
-    F_QUADS = 2u,    // Quad leaves
-    F_FRAMES = 4u,   // Translate / RotateY
-    F_MEDIA = 8u,    // ConstantMedium
-    F_TEXTURES = 16u // Checker / Image / Noise textures (without it every texture is a SolidColor)
-};
-constexpr uint32_t F_ALL = 31u;
-
 // LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = + sphere table; 3 = + quad table
 // ORDERED: walk the compiler's own trees nearest child first (scenes without a ConstantMedium), else the threaded
 // records in the reference's order
@@ -523,7 +436,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
 
     Counts cn{};
     Rng rng;
-    rng.state = 0;
+    rng.x = 0; rng.y = 0;
 
     // ---- per-lane path state ----
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1); // current-frame ray
@@ -1288,9 +1201,10 @@ __global__ void sum_samples_kernel(const KParams P) {
     dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
 }
 
-// frame-end reassembly: [shard][local tile][64][3] -> row-major frame
+// frame-end reassembly: [shard][local tile][64][3] -> row-major frame (T = double: channel sums; uint8_t: resolved RGB8)
+template <class T>
 __global__ void tiles_to_frame_kernel(int32_t w, int32_t h, int32_t tiles_x, int32_t shard_count, int64_t shard_stride,
-                                      const double *__restrict__ gathered, double *__restrict__ frame) {
+                                      const T *__restrict__ gathered, T *__restrict__ frame) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per pixel
     if (idx >= (int64_t)w * h) return;
     const int32_t i = (int32_t)(idx % w), j = (int32_t)(idx / w);
@@ -1302,17 +1216,11 @@ __global__ void tiles_to_frame_kernel(int32_t w, int32_t h, int32_t tiles_x, int
     frame[idx * 3 + 2] = gathered[src + 2];
 }
 
-// color_to_rgb(c / spp) (src/renderer.rs:55-58, src/color.rs:12-19)
+// color_to_rgb(c / spp) (src/renderer.rs:55-58, src/color.rs:12-19): the host library's code (rt_shared_math.h)
 __global__ void resolve_rgb8_kernel(int64_t n_values, double inv_spp, const double *__restrict__ sum, uint8_t *__restrict__ rgb) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_values) return;
-    const double g = pow(sum[idx] * inv_spp, 1.0 / 2.2);
-    uint8_t b = 0;
-    if (g == g) {
-        const double c = g < 0.0 ? 0.0 : (g > 0.999 ? 0.999 : g);
-        b = (uint8_t)(256.0 * c);
-    }
-    rgb[idx] = b;
+    rgb[idx] = rtm::rt_quantise(rtm::rt_gamma_encode(sum[idx] * inv_spp));
 }
 
 // test hook: the conservative f32 box test against the exact f64 one on caller-supplied rays and boxes
@@ -1359,10 +1267,10 @@ __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restric
     case RT_DEBUG_DIV: r = x / y; break;
     case RT_DEBUG_MUL_ADD: r = x * y + x; break; // must be two roundings (no contraction)
     case RT_DEBUG_RNG_RANDOM: { // x, y carry the key's and the draw number's bits
-        Rng g; g.state = f2u(x) + (f2u(y) ) * RNG_GAMMA; r = g.random(); break;
+        Rng g; g.start_key(f2u(x)); for (uint64_t i = 0; i < f2u(y); ++i) g.next(); r = g.random(); break;
     }
     case RT_DEBUG_RNG_RANGE: {
-        Rng g; g.state = f2u(x) + (f2u(y)) * RNG_GAMMA; r = g.range(-1.0, 1.0); break;
+        Rng g; g.start_key(f2u(x)); for (uint64_t i = 0; i < f2u(y); ++i) g.next(); r = g.range(-1.0, 1.0); break;
     }
     default: r = 0.0;
     }
@@ -1372,152 +1280,17 @@ __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restric
 } // namespace
 
 // =====================================================================================================
-// Host side: the C ABI
+// Host side of this file: which instantiation renders what, and the launches of the small kernels
 // =====================================================================================================
-namespace {
+namespace rtk {
 
-thread_local std::string g_last_error;
-std::mutex g_stage_profile_mu;
-unsigned long long g_stage_profile[PROF_SLOTS * 3] = {0}; // of the last counted render: per slot (rounds, active lanes, cycles)
-
-uint64_t rtk_host_mix64(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
-
-int fail(int status, const std::string &msg) {
-    g_last_error = msg;
-    return status;
-}
-#define HIP_TRY(expr)                                                                                          \
-    do {                                                                                                       \
-        hipError_t _e = (expr);                                                                                \
-        if (_e != hipSuccess)                                                                                  \
-            return fail(_e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                         \
-                        std::string(#expr) + ": " + hipGetErrorString(_e));                                    \
-    } while (0)
-
-struct Workspace {
-    double *att_stack = nullptr;
-    size_t att_bytes = 0;
-    double *world_slots = nullptr; // [6][n_threads]
-    size_t world_bytes = 0;
-    double *samples = nullptr; // sample buffer of one launch
-    size_t sample_bytes = 0;
-    uint32_t *job_counter = nullptr;
-    unsigned long long *counters = nullptr;
-};
-
-// Scheduler knobs (64ths of the live lanes a deferred stage must have queued; box rounds per decision).
-// Defaults were picked on MI355X with bench.py (DESIGN.md "Scheduler"); the RT_* variables are for tuning runs.
-// Scheduler knobs (64ths of the live lanes a deferred stage must have queued / the box loop needs to keep running).
-// The best values depend on the stage mix, so there is one preset per kernel instantiation, each picked with
-// tools/tune.py on MI355X (DESIGN.md "Scheduler"); a value >= 0 in `forced` (RT_TH_* variables, rt_debug_set_tuning)
-// overrides all presets.
-struct Thresholds { uint32_t prim, other, shade, box, newjob; };
-struct Tuning {
-    Thresholds general{8, 8, 48, 8, 0};
-    Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
-    Thresholds spheres_solid{8, 16, 24, 16, 32}; // random-spheres
-    Thresholds quads_frames{8, 16, 40, 4, 8};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
-    int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
-    int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
-    int refit = 1;   // 0: walk the reference's own (looser) boxes
-    int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
-                     // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
-    int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
-    OrderedOptions ordered_options;
-    size_t sample_buffer_bytes = (size_t)16 << 30;
-    Tuning() {
-        auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
-        env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-        if (const char *e = getenv("RT_USE_LDS")) use_lds = atoi(e);
-        if (const char *e = getenv("RT_REFIT")) refit = atoi(e);
-        if (const char *e = getenv("RT_ORDERED")) ordered = atoi(e);
-        if (const char *e = getenv("RT_JOBS_PER_GRAB")) jobs_per_grab = atoi(e);
-        if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
-        if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
-        if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
-        if (const char *e = getenv("RT_SAH_INSTANCE")) ordered_options.cost_instance = atof(e);
-        if (const char *e = getenv("RT_SAMPLE_BUFFER_MB")) sample_buffer_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
-    }
-    Thresholds pick(const Thresholds &preset) const {
-        Thresholds t = preset;
-        if (forced[0] >= 0) t.prim = (uint32_t)forced[0];
-        if (forced[1] >= 0) t.other = (uint32_t)forced[1];
-        if (forced[2] >= 0) t.shade = (uint32_t)forced[2];
-        if (forced[3] >= 0) t.box = (uint32_t)forced[3];
-        if (forced[4] >= 0) t.newjob = (uint32_t)forced[4];
-        return t;
-    }
-};
-Tuning &tuning() { static Tuning t; return t; }
-
-template <class T> struct DeviceArray {
-    T *ptr = nullptr;
-    size_t bytes = 0;
-};
-
-} // namespace
-
-struct rt_scene {
-    int device = 0;
-    int n_cus = 0;
-    int blocks_per_cu[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; // [LDS level][counted?]
-    DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
-    uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
-    bool has_instances = false;
-    int lds_level = 0;                          // 0 nothing fits, 1 nodes, 2 nodes + spheres, 3 nodes + spheres + quads
-    uint32_t features = F_ALL;                  // Feature bits the scene uses
-    uint32_t lds_prefix_bytes[4] = {0, 0, 0, 0}; // image prefix each LDS level copies in
-    DeviceArray<Node32> nodes;
-    DeviceArray<Sphere> spheres;
-    DeviceArray<Quad> quads;
-    DeviceArray<Instance> insts;
-    DeviceArray<Medium> media;
-    DeviceArray<DMaterial> mats;
-    DeviceArray<rt_texture> texs;
-    DeviceArray<rt_perlin> perlins;
-    DeviceArray<ImageRef> images;
-    DeviceArray<uint8_t> texels;
-    DeviceArray<double> lut;
-    uint32_t n_nodes = 0;
-    bool ordered = false;                        // ordered layout (rt_ordered.hpp): onodes instead of nodes
-    DeviceArray<uint4> oimage;                   // ordered layout: the tables of load_opair (global copy)
-    DeviceArray<OSeq> oseq;                      // ... and the world frame's sequence
-    uint32_t n_oseq = 0;
-    float box_extent = 0.0f;                     // largest |coordinate| of any box of the ordered layout
-    DeviceArray<uint4> aux_image;                // materials | textures | frames | media | Perlin for the AUX kernels (0 bytes: not used)
-    uint32_t aux_bytes = 0, aux_off[5] = {0, 0, 0, 0, 0};
-    uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
-    rt_scene_stats stats{};
-    std::mutex mu;
-    std::map<hipStream_t, Workspace> workspaces; // one per stream: launches on a stream are ordered
-    std::mutex host_render_mu;                   // rt_render (host-buffer form) calls on one scene run one at a time
-};
-
-namespace {
-
-constexpr int GLOBAL_THREADS = 256;             // scene gathered from global memory: 256-thread blocks
-#ifndef RT_LDS_THREADS
-#define RT_LDS_THREADS 1024 // 16 waves = 4 per SIMD (tools/tune.py: 512 -> 1381, 768 -> 1774, 1024 -> 1921 Msamples/s on C2 at 48 spp)
-#endif
-constexpr int LDS_THREADS = RT_LDS_THREADS;       // scene in LDS: one 12-wave workgroup per CU shares the copy
-constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
-
-// The kernel instantiations that exist: the general one (every feature) at each LDS level, plus two specialised
-// ones for scenes that fit the LDS entirely and use a subset of the features (BASELINE configs 1/2 and 3).
-constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
-constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
     if (lds == 3 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
     if (lds == 3 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
     (void)ordered;
     return F_ALL;
 }
-const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
+const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
 #define RT_PICK(L, T, F, O) (counted ? (const void *)path_kernel<true, L, T, F, O> : (const void *)path_kernel<false, L, T, F, O>)
     if (ordered && lds == 0 && aux)
         return counted ? (const void *)path_kernel<true, 0, GLOBAL_THREADS, F_ALL, true, true> : (const void *)path_kernel<false, 0, GLOBAL_THREADS, F_ALL, true, true>;
@@ -1540,715 +1313,30 @@ const void *kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool 
     return RT_PICK(0, GLOBAL_THREADS, F_ALL, false);
 #undef RT_PICK
 }
-uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return s->lds_prefix_bytes[lds]; }
-// the LDS image, then (ordered walk) the per-lane stacks: 2-byte entries beside an LDS-resident scene, else 4-byte
-size_t stack_bytes(const rt_scene *s, int lds) {
-    if (!s->ordered) return 0;
-    return (size_t)s->o_stack * (lds ? (size_t)LDS_THREADS * 2u : (size_t)GLOBAL_THREADS * 4u);
-}
-size_t prof_bytes(int lds) { return (size_t)((lds ? LDS_THREADS : GLOBAL_THREADS) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
-size_t seq_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 15u) & ~(size_t)15u; }
-size_t aux_offset(const rt_scene *s, int lds) { return (seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u) + 15u) & ~(size_t)15u; }
-bool aux_in_lds(const rt_scene *s, int lds) { return lds == 0 && s->aux_bytes != 0; }
-size_t prof_offset(const rt_scene *s, int lds) { return aux_offset(s, lds) + (aux_in_lds(s, lds) ? s->aux_bytes : 0u); }
-size_t dynamic_lds_bytes(const rt_scene *s, int lds, bool counted) {
-    return prof_offset(s, lds) + (counted ? prof_bytes(lds) : 0);
-}
 
-template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
-    dst.bytes = src.size() * sizeof(T);
-    // never hand the kernel a null table: allocate at least one element
-    const size_t alloc = dst.bytes ? dst.bytes : sizeof(T);
-    HIP_TRY(hipMalloc((void **)&dst.ptr, alloc));
-    if (dst.bytes) HIP_TRY(hipMemcpy(dst.ptr, src.data(), dst.bytes, hipMemcpyHostToDevice));
-    else HIP_TRY(hipMemset(dst.ptr, 0, alloc));
-    return RT_OK;
+void launch_sum_samples(const KParams &K, unsigned grid, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_samples_kernel, dim3(grid), dim3(256), 0, stream, K);
 }
-
-bool texture_needs_uv(const std::vector<rt_texture> &texs, int32_t t, int depth = 0) {
-    if (t < 0 || depth > 16) return false;
-    const rt_texture &x = texs[(size_t)t];
-    if (x.kind == RT_TEXTURE_IMAGE) return true;
-    if (x.kind == RT_TEXTURE_CHECKER) return texture_needs_uv(texs, x.even, depth + 1) || texture_needs_uv(texs, x.odd, depth + 1);
-    return false;
+void launch_tiles_to_frame(int32_t w, int32_t h, int32_t tiles_x, int32_t shard_count, int64_t shard_stride, const double *gathered,
+                           double *frame, hipStream_t stream) {
+    const int64_t n = (int64_t)w * h;
+    hipLaunchKernelGGL(tiles_to_frame_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, h, tiles_x, shard_count,
+                       shard_stride, gathered, frame);
+}
+void launch_tiles_to_frame_rgb8(int32_t w, int32_t h, int32_t tiles_x, int32_t shard_count, int64_t shard_stride, const uint8_t *gathered,
+                                uint8_t *frame, hipStream_t stream) {
+    const int64_t n = (int64_t)w * h;
+    hipLaunchKernelGGL(tiles_to_frame_kernel<uint8_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, h, tiles_x, shard_count,
+                       shard_stride, gathered, frame);
+}
+void launch_resolve_rgb8(int64_t n_values, double inv_spp, const double *sum, uint8_t *rgb, hipStream_t stream) {
+    hipLaunchKernelGGL(resolve_rgb8_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, stream, n_values, inv_spp, sum, rgb);
+}
+void launch_debug_box(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *exact_hit, uint8_t *f32_hit) {
+    hipLaunchKernelGGL(debug_box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, rays, boxes, tmin, tmax, exact_hit, f32_hit);
+}
+void launch_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out) {
+    hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, a, b, out);
 }
 
-void free_scene(rt_scene *s) {
-    if (!s) return;
-    (void)hipSetDevice(s->device);
-    for (auto &kv : s->workspaces) {
-        (void)hipFree(kv.second.att_stack);
-        (void)hipFree(kv.second.samples);
-        (void)hipFree(kv.second.world_slots);
-        (void)hipFree(kv.second.job_counter);
-        (void)hipFree(kv.second.counters);
-    }
-    (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
-    (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
-    (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr); (void)hipFree(s->aux_image.ptr);
-    delete s;
-}
-
-int64_t tiles_total(int32_t w, int32_t h) {
-    return (int64_t)((w + RT_TILE_W - 1) / RT_TILE_W) * ((h + RT_TILE_H - 1) / RT_TILE_H);
-}
-int64_t tiles_local(int32_t w, int32_t h, int32_t shard_index, int32_t shard_count) {
-    return (tiles_total(w, h) - shard_index + shard_count - 1) / shard_count;
-}
-
-int normalise_params(const rt_camera *cam, rt_render_params &p) {
-    if (cam->image_width <= 0 || cam->image_height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: empty image");
-    if ((int64_t)cam->image_width * cam->image_height > 0x7fffffffll)
-        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: image has more than 2^31 pixels");
-    if (p.sample_end <= 0) p.sample_end = cam->samples_per_pixel;
-    if (p.max_depth <= 0) p.max_depth = cam->max_depth;
-    if (p.shard_count <= 0) p.shard_count = 1;
-    if (p.sample_begin < 0 || p.sample_end < p.sample_begin) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: bad sample range");
-    if (p.shard_index < 0 || p.shard_index >= p.shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: shard_index out of range");
-    if (p.out_layout != RT_OUT_FRAME && p.out_layout != RT_OUT_TILES) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: unknown out_layout");
-    if (p.max_depth <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: max_depth must be positive");
-    return RT_OK;
-}
-
-int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, double *d_out, hipStream_t stream,
-                  rt_counters *out_counters) {
-    int rc = normalise_params(camera, p);
-    if (rc != RT_OK) return rc;
-    HIP_TRY(hipSetDevice(scene->device));
-    const bool counted = out_counters != nullptr;
-    const int64_t n_local = tiles_local(camera->image_width, camera->image_height, p.shard_index, p.shard_count);
-    const int64_t n_samples_total = (int64_t)p.sample_end - p.sample_begin;
-    if (n_local <= 0 || n_samples_total <= 0) {
-        if (out_counters) *out_counters = rt_counters{};
-        return RT_OK;
-    }
-    const Tuning tn = tuning();
-
-    // samples per launch: bounded by the sample buffer and by the 32-bit job index
-    const int64_t bytes_per_sample_row = n_local * 64 * 3 * (int64_t)sizeof(double);
-    int64_t chunk = (int64_t)(tn.sample_buffer_bytes / (size_t)bytes_per_sample_row);
-    const int64_t max_by_index = ((int64_t)1 << 31) / (n_local * 64);
-    if (chunk > max_by_index) chunk = max_by_index;
-    if (chunk > n_samples_total) chunk = n_samples_total;
-    if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
-
-    const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
-    const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-    const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
-    const size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
-    // persistent grid: every resident wave pulls jobs until none are left
-    int64_t grid = (int64_t)scene->n_cus * bpc;
-    const int64_t waves_per_block = threads / 64;
-    const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_GRAB * waves_per_block - 1) / (MIN_JOBS_PER_GRAB * waves_per_block);
-    if (grid > max_useful) grid = max_useful;
-    if (grid < 1) grid = 1;
-    const uint32_t n_threads = (uint32_t)(grid * threads);
-
-    Workspace ws;
-    {
-        std::lock_guard<std::mutex> lock(scene->mu);
-        Workspace &w = scene->workspaces[stream];
-        const size_t need_att = ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double); // + a light's emitted colour
-        if (need_att / sizeof(double) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the attenuation stack's 32-bit indices");
-        const size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
-        if (w.att_bytes < need_att || w.sample_bytes < need_samples) HIP_TRY(hipStreamSynchronize(stream));
-        if (w.att_bytes < need_att) {
-            if (w.att_stack) HIP_TRY(hipFree(w.att_stack));
-            w.att_stack = nullptr; w.att_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&w.att_stack, need_att));
-            w.att_bytes = need_att;
-        }
-        const size_t need_world = (size_t)6 * n_threads * sizeof(double);
-        if (w.world_bytes < need_world) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (w.world_slots) HIP_TRY(hipFree(w.world_slots));
-            w.world_slots = nullptr; w.world_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&w.world_slots, need_world));
-            w.world_bytes = need_world;
-        }
-        if (w.sample_bytes < need_samples) {
-            if (w.samples) HIP_TRY(hipFree(w.samples));
-            w.samples = nullptr; w.sample_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&w.samples, need_samples));
-            w.sample_bytes = need_samples;
-        }
-        if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
-        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 40 * sizeof(unsigned long long)));
-        ws = w;
-    }
-    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 40 * sizeof(unsigned long long), stream));
-
-    KParams K{};
-    K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
-    K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
-    K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
-    K.out = d_out;
-    K.samples = ws.samples;
-    K.att_stack = ws.att_stack;
-    K.job_counter = ws.job_counter;
-    K.counters = counted ? ws.counters : nullptr;
-    K.cam = *camera;
-    K.seed_mixed = rtk_host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
-    K.n_nodes = scene->n_nodes;
-    K.n_threads = n_threads;
-    K.max_depth = p.max_depth;
-    K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
-    K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
-    K.inv_tiles_x = 1.0 / (double)K.tiles_x;
-    K.n_local_tiles = (uint32_t)n_local;
-    K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
-    K.lds_off_node_b = scene->lds_off_node_b;
-    K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
-    K.world_slots = ws.world_slots;
-    K.box_extent = scene->box_extent;
-    K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
-    K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
-    K.aux_image = scene->aux_image.ptr; K.aux_bytes = scene->aux_bytes; K.lds_aux_off = (uint32_t)aux_offset(scene, lds);
-    K.aux_off_mats = scene->aux_off[0]; K.aux_off_texs = scene->aux_off[1]; K.aux_off_insts = scene->aux_off[2];
-    K.aux_off_media = scene->aux_off[3]; K.aux_off_perlins = scene->aux_off[4];
-    K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
-    {
-        const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : (scene->ordered ? tn.ordered_general : tn.general)));
-        K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
-    }
-
-    const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
-    for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk) {
-        const int64_t ns = (p.sample_end - sb) < chunk ? (p.sample_end - sb) : chunk;
-        K.sample_begin = (int32_t)sb;
-        K.n_samples = (uint32_t)ns;
-        K.n_jobs = (uint32_t)(n_local * 64 * ns);
-        K.inv_n_samples = 1.0 / (double)ns;
-        {
-            // ~32 grabs per wave or more, rounded down to a multiple of 64 within [MIN, MAX]
-            const int64_t waves = grid * waves_per_block;
-            int64_t per_grab = (int64_t)K.n_jobs / (waves * 32);
-            if (tn.jobs_per_grab > 0) per_grab = tn.jobs_per_grab;
-            per_grab = per_grab / 64 * 64;
-            if (per_grab > MAX_JOBS_PER_GRAB) per_grab = MAX_JOBS_PER_GRAB;
-            if (per_grab < MIN_JOBS_PER_GRAB) per_grab = MIN_JOBS_PER_GRAB;
-            K.jobs_per_grab = (uint32_t)per_grab;
-        }
-        K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
-        HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
-        {
-            void *args[] = {(void *)&K};
-            HIP_TRY(hipLaunchKernel(kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered, aux_in_lds(scene, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
-        }
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(sum_samples_kernel, dim3(sum_grid), dim3(256), 0, stream, K);
-        HIP_TRY(hipGetLastError());
-    }
-
-    if (counted) {
-        unsigned long long host[40];
-        HIP_TRY(hipMemcpyAsync(host, ws.counters, sizeof host, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        {
-            std::lock_guard<std::mutex> lock(g_stage_profile_mu);
-            for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) g_stage_profile[q] = host[10 + q];
-        }
-        out_counters->samples = host[0]; out_counters->rays = host[1]; out_counters->node_visits = host[2];
-        out_counters->sphere_tests = host[3]; out_counters->quad_tests = host[4]; out_counters->medium_visits = host[5];
-        out_counters->rng_draws = host[6]; out_counters->noise_evals = host[7]; out_counters->image_lookups = host[8];
-        out_counters->instance_enters = host[9];
-    }
-    return RT_OK;
-}
-
-} // namespace
-
-extern "C" {
-
-const char *rt_last_error(void) { return g_last_error.c_str(); }
-const char *rt_version(void) { return "rt_amd 0.1 (gfx950, abi 1)"; }
-
-int rt_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-int64_t rt_out_size(int32_t width, int32_t height, int32_t out_layout, int32_t shard_index, int32_t shard_count) {
-    if (width <= 0 || height <= 0) return -1;
-    if (shard_count <= 0) shard_count = 1;
-    if (shard_index < 0 || shard_index >= shard_count) return -1;
-    if (out_layout == RT_OUT_FRAME) return (int64_t)width * height * 3;
-    if (out_layout == RT_OUT_TILES) return tiles_local(width, height, shard_index, shard_count) * RT_TILE_W * RT_TILE_H * 3;
-    return -1;
-}
-
-// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py), own trees vs reference
-// order, Msamples/s: two_spheres 3978 / 4813, earth 15970 / 19317, two_perlin_spheres 2349 / 2651, simple_light 3060 /
-// 3322 (1-4 primitives: a tree and a stack are overhead); quads 15790 / 14393, cornell_box 2206 / 1967, random_balls 3557 /
-// 2038, final_scene 821 / 624; cornell_smoke 496 / 736 (18 quads, and two media whose rotated-box boundaries are walked as
-// trees of their own, twice per visit).
-static bool ordered_walk_pays(const CompiledScene &cs) {
-    const size_t prims = cs.spheres.size() + cs.quads.size();
-    if (prims <= 4) return false;
-    bool general_boundary = false;
-    for (const Node &n : cs.nodes)
-        if ((n.kind & NODE_KIND_MASK) == NK_MEDIUM_ENTER) general_boundary = true;
-    if (general_boundary && prims < 64) return false;
-    return true;
-}
-
-int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) {
-    if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
-    *out_scene = nullptr;
-    CompiledScene cs;
-    try {
-        cs = compile_scene(*desc, tuning().refit != 0);
-        if (tuning().ordered == 2 || (tuning().ordered == 1 && ordered_walk_pays(cs))) build_ordered(cs, tuning().ordered_options);
-    } catch (const CompileError &e) {
-        return fail(e.status, e.what());
-    } catch (const std::exception &e) {
-        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_scene_create: ") + e.what());
-    }
-    const int ndev = rt_device_count();
-    if (ndev <= 0) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: no HIP device is visible (this library has no CPU path)");
-    if (device < 0 || device >= ndev) return fail(RT_ERR_NO_DEVICE, "rt_scene_create: device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
-
-    rt_scene *s = new rt_scene();
-    s->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "hipGetDeviceProperties failed"); }
-    s->n_cus = prop.multiProcessorCount;
-    s->has_instances = !cs.instances.empty();
-    s->features = (cs.spheres.empty() ? 0u : F_SPHERES) | (cs.quads.empty() ? 0u : F_QUADS) | (cs.instances.empty() ? 0u : F_FRAMES) |
-                  (cs.media.empty() ? 0u : F_MEDIA);
-    for (const auto &t : cs.textures)
-        if (t.kind != RT_TEXTURE_SOLID) s->features |= F_TEXTURES;
-    s->ordered = cs.ordered;
-    // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
-    s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
-    s->n_oseq = (uint32_t)cs.oseq.size();
-    for (const ONode &nd : cs.onodes)
-        for (int k = 0; k < 6; ++k) {
-            if ((nd.c[0] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b0[k]));
-            if ((nd.c[1] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b1[k]));
-        }
-    for (const OSeq &st : cs.oseq)
-        for (int k = 0; k < 6; ++k) s->box_extent = std::fmax(s->box_extent, std::fabs(st.box[k]));
-    s->o_stack = cs.ordered_stack;
-    // Node tables (load_node / load_opair): threaded records as two 16-byte halves, ordered records as six 16-byte plane
-    // tables and an 8-byte reference table.  LDS image = node tables | spheres | quads; every LDS level copies a prefix.
-    {
-        const size_t n = cs.ordered ? cs.onodes.size() : cs.nodes32.size();
-        const size_t off_b = n * 16; // bytes of one 16-byte-per-record table
-        const size_t off_sph = cs.ordered ? ((n * (6 * 16 + 8) + 15u) & ~(size_t)15u) : n * 32;
-        std::vector<uint4> tables(off_sph / 16);
-        {
-            unsigned char *base = reinterpret_cast<unsigned char *>(tables.data());
-            if (cs.ordered) {
-                for (size_t i = 0; i < n; ++i) {
-                    const ONode &nd = cs.onodes[i];
-                    for (int ax = 0; ax < 3; ++ax) {
-                        const float lo0 = nd.b0[2 * ax], hi0 = nd.b0[2 * ax + 1], lo1 = nd.b1[2 * ax], hi1 = nd.b1[2 * ax + 1];
-                        const float plus[4] = {lo0, lo1, hi0, hi1}, minus[4] = {hi0, hi1, lo0, lo1};
-                        memcpy(base + (size_t)(2 * ax) * off_b + i * 16, plus, 16);
-                        memcpy(base + (size_t)(2 * ax + 1) * off_b + i * 16, minus, 16);
-                    }
-                    memcpy(base + 6 * off_b + i * 8, nd.c, 8);
-                }
-            } else {
-                const unsigned char *src = reinterpret_cast<const unsigned char *>(cs.nodes32.data());
-                for (size_t i = 0; i < n; ++i)
-                    for (size_t q = 0; q < 2; ++q) memcpy(base + q * off_b + i * 16, src + (i * 2 + q) * 16, 16);
-            }
-        }
-        if (cs.ordered) { // the global copy: one 128-byte line per record (load_opair<0>)
-            std::vector<uint4> lines(n * 8);
-            unsigned char *dst = reinterpret_cast<unsigned char *>(lines.data());
-            const unsigned char *tab = reinterpret_cast<const unsigned char *>(tables.data());
-            for (size_t i = 0; i < n; ++i) {
-                for (size_t q = 0; q < 6; ++q) memcpy(dst + i * 128 + q * 16, tab + q * off_b + i * 16, 16);
-                memcpy(dst + i * 128 + 96, tab + 6 * off_b + i * 8, 8);
-            }
-            int urc = upload(s->oimage, lines);
-            if (urc != RT_OK) { free_scene(s); return urc; }
-        }
-        s->lds_off_node_b = (uint32_t)off_b;
-        const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
-        const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
-        const size_t stack = stack_bytes(s, 1);
-        // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
-        // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
-        const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
-        s->lds_level = total + stack <= budget ? 3 : (off_sph + stack <= budget ? 1 : 0);
-        if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits
-        if (s->lds_level) {
-            const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
-            std::vector<uint4> img(used / 16);
-            unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
-            memcpy(base, tables.data(), off_sph);
-            if (s->lds_level >= 2 && !cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
-            if (s->lds_level == 3 && !cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
-            int urc = upload(s->lds_image, img);
-            if (urc != RT_OK) { free_scene(s); return urc; }
-            s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;
-            s->lds_image_bytes = (uint32_t)used;
-            s->lds_prefix_bytes[1] = (uint32_t)off_sph;
-            s->lds_prefix_bytes[2] = (uint32_t)((off_quads + 15u) & ~(size_t)15u);
-            s->lds_prefix_bytes[3] = (uint32_t)total;
-            for (int l = s->lds_level + 1; l < 4; ++l) s->lds_prefix_bytes[l] = 0;
-        }
-    }
-    std::vector<DMaterial> mats(cs.materials.size());
-    for (size_t i = 0; i < mats.size(); ++i) {
-        const rt_material &m = cs.materials[i];
-        DMaterial d{};
-        d.kind = (uint32_t)m.kind;
-        d.texture = m.texture >= 0 ? (uint32_t)m.texture : 0u;
-        d.needs_uv = texture_needs_uv(cs.textures, m.texture) ? 1u : 0u;
-        d.albedo[0] = m.albedo.x; d.albedo[1] = m.albedo.y; d.albedo[2] = m.albedo.z;
-        if (m.kind != RT_MATERIAL_METAL && m.kind != RT_MATERIAL_DIELECTRIC && m.texture >= 0 &&
-            cs.textures[(size_t)m.texture].kind == RT_TEXTURE_SOLID) {
-            const rt_vec3 &c = cs.textures[(size_t)m.texture].color;
-            d.solid = 1u;
-            d.albedo[0] = c.x; d.albedo[1] = c.y; d.albedo[2] = c.z;
-        }
-        d.fuzz = m.fuzz;
-        d.ir = m.ir;
-        mats[i] = d;
-    }
-
-    // AUX image (path_kernel's AUX): the small tables, for ordered scenes whose big tables stay in global memory
-    {
-        auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
-        const size_t o_mats = 0, o_texs = align16(o_mats + mats.size() * sizeof(DMaterial)),
-                     o_insts = align16(o_texs + cs.textures.size() * sizeof(rt_texture)),
-                     o_media = align16(o_insts + cs.instances.size() * sizeof(Instance)),
-                     o_perlins = align16(o_media + cs.media.size() * sizeof(Medium)),
-                     total = align16(o_perlins + cs.perlins.size() * sizeof(rt_perlin));
-        if (s->ordered && s->lds_level == 0 && total > 0 && total <= 24 * 1024) {
-            std::vector<uint4> img(total / 16);
-            unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
-            if (!mats.empty()) memcpy(base + o_mats, mats.data(), mats.size() * sizeof(DMaterial));
-            if (!cs.textures.empty()) memcpy(base + o_texs, cs.textures.data(), cs.textures.size() * sizeof(rt_texture));
-            if (!cs.instances.empty()) memcpy(base + o_insts, cs.instances.data(), cs.instances.size() * sizeof(Instance));
-            if (!cs.media.empty()) memcpy(base + o_media, cs.media.data(), cs.media.size() * sizeof(Medium));
-            if (!cs.perlins.empty()) memcpy(base + o_perlins, cs.perlins.data(), cs.perlins.size() * sizeof(rt_perlin));
-            int urc = upload(s->aux_image, img);
-            if (urc != RT_OK) { free_scene(s); return urc; }
-            s->aux_bytes = (uint32_t)total;
-            s->aux_off[0] = (uint32_t)o_mats; s->aux_off[1] = (uint32_t)o_texs; s->aux_off[2] = (uint32_t)o_insts;
-            s->aux_off[3] = (uint32_t)o_media; s->aux_off[4] = (uint32_t)o_perlins;
-        }
-    }
-    for (int lds = 0; lds < 4; ++lds)
-        for (int counted = 0; counted < 2; ++counted) {
-            if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
-            const void *fn = kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered, aux_in_lds(s, lds));
-            const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
-            const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
-            if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            int b = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, fn, threads, dyn) != hipSuccess || b < 1) b = 1;
-            s->blocks_per_cu[lds][counted] = b;
-        }
-
-    int rc = RT_OK;
-    if ((rc = upload(s->nodes, cs.nodes32)) != RT_OK || (rc = upload(s->oseq, cs.oseq)) != RT_OK ||
-        (rc = upload(s->spheres, cs.spheres)) != RT_OK ||
-        (rc = upload(s->quads, cs.quads)) != RT_OK || (rc = upload(s->insts, cs.instances)) != RT_OK ||
-        (rc = upload(s->media, cs.media)) != RT_OK || (rc = upload(s->mats, mats)) != RT_OK ||
-        (rc = upload(s->texs, cs.textures)) != RT_OK || (rc = upload(s->perlins, cs.perlins)) != RT_OK ||
-        (rc = upload(s->images, cs.images)) != RT_OK || (rc = upload(s->texels, cs.texels)) != RT_OK ||
-        (rc = upload(s->lut, cs.srgb_lut)) != RT_OK) {
-        free_scene(s);
-        return rc;
-    }
-    s->n_nodes = (uint32_t)cs.nodes.size();
-    rt_scene_stats &st = s->stats;
-    st.node_bytes = cs.ordered ? s->oimage.bytes : s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
-    st.instance_bytes = s->insts.bytes; st.medium_bytes = s->media.bytes; st.material_bytes = s->mats.bytes;
-    st.texture_bytes = s->texs.bytes; st.perlin_bytes = s->perlins.bytes; st.image_bytes = s->texels.bytes;
-    st.n_nodes = (uint32_t)(cs.ordered ? cs.onodes.size() : cs.nodes.size()); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
-    st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
-    st.max_instance_depth = cs.max_instance_depth;
-    st.lds_nodes = s->lds_level ? st.n_nodes : 0; st.lds_bytes = s->lds_level ? (uint32_t)dynamic_lds_bytes(s, s->lds_level, false) : 0;
-    st.ordered = cs.ordered ? 1u : 0u; st.stack_entries = cs.ordered ? cs.ordered_stack : 0u;
-    *out_scene = s;
-    return RT_OK;
-}
-
-void rt_scene_destroy(rt_scene *scene) { free_scene(scene); }
-
-int rt_scene_get_stats(const rt_scene *scene, rt_scene_stats *out) {
-    if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_get_stats: null argument");
-    *out = scene->stats;
-    return RT_OK;
-}
-
-int rt_render_device(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params, double *d_out_rgb_sum,
-                     void *hip_stream) {
-    if (!scene || !camera || !params || !d_out_rgb_sum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device: null argument");
-    return launch_render(const_cast<rt_scene *>(scene), camera, *params, d_out_rgb_sum, (hipStream_t)hip_stream, nullptr);
-}
-
-int rt_render_device_counted(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params,
-                             double *d_out_rgb_sum, void *hip_stream, rt_counters *out_counters) {
-    if (!scene || !camera || !params || !d_out_rgb_sum || !out_counters)
-        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_device_counted: null argument");
-    return launch_render(const_cast<rt_scene *>(scene), camera, *params, d_out_rgb_sum, (hipStream_t)hip_stream, out_counters);
-}
-
-int rt_render(const rt_scene *scene, const rt_camera *camera, const rt_render_params *params, double *out_rgb_sum) {
-    if (!scene || !camera || !params || !out_rgb_sum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_render: null argument");
-    rt_render_params p = *params;
-    int rc = normalise_params(camera, p);
-    if (rc != RT_OK) return rc;
-    rt_scene *s = const_cast<rt_scene *>(scene);
-    std::lock_guard<std::mutex> serial(s->host_render_mu);
-    HIP_TRY(hipSetDevice(s->device));
-    const int32_t w = camera->image_width, h = camera->image_height;
-    // on the device the shard always renders into its compact tile buffer; the requested layout is produced on the host
-    rt_render_params dp = p;
-    dp.out_layout = RT_OUT_TILES;
-    const int64_t n_tiles_vals = rt_out_size(w, h, RT_OUT_TILES, p.shard_index, p.shard_count);
-    if (n_tiles_vals <= 0) return RT_OK;
-    const int32_t tiles_x = (w + RT_TILE_W - 1) / RT_TILE_W;
-    const int64_t n_local = n_tiles_vals / (RT_TILE_W * RT_TILE_H * 3);
-    std::vector<double> tiles((size_t)n_tiles_vals);
-    auto for_each_pixel = [&](auto &&fn) {
-        for (int64_t lt = 0; lt < n_local; ++lt) {
-            const int64_t k = lt * p.shard_count + p.shard_index;
-            const int32_t x0 = (int32_t)(k % tiles_x) * RT_TILE_W, y0 = (int32_t)(k / tiles_x) * RT_TILE_H;
-            for (int32_t ty = 0; ty < RT_TILE_H; ++ty)
-                for (int32_t tx = 0; tx < RT_TILE_W; ++tx) {
-                    const int32_t i = x0 + tx, j = y0 + ty;
-                    if (i >= w || j >= h) continue;
-                    fn(&tiles[(size_t)((lt * RT_TILE_H + ty) * RT_TILE_W + tx) * 3u], ((size_t)j * w + i) * 3u);
-                }
-        }
-    };
-    if (p.accumulate) { // seed the device buffer with the caller's running sums
-        if (p.out_layout == RT_OUT_TILES) std::copy(out_rgb_sum, out_rgb_sum + n_tiles_vals, tiles.begin());
-        else for_each_pixel([&](double *t, size_t f) { t[0] = out_rgb_sum[f]; t[1] = out_rgb_sum[f + 1]; t[2] = out_rgb_sum[f + 2]; });
-    }
-    double *d_tiles = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_tiles, (size_t)n_tiles_vals * sizeof(double)));
-    hipStream_t stream = nullptr;
-    rc = RT_OK;
-    do {
-        if (p.accumulate && hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-            rc = fail(RT_ERR_HIP, "rt_render: upload of running sums failed");
-            break;
-        }
-        rc = launch_render(s, camera, dp, d_tiles, stream, nullptr);
-        if (rc != RT_OK) break;
-        hipError_t e = hipMemcpy(tiles.data(), d_tiles, tiles.size() * sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { rc = fail(RT_ERR_HIP, std::string("rt_render: ") + hipGetErrorString(e)); break; }
-    } while (0);
-    (void)hipFree(d_tiles);
-    if (rc != RT_OK) return rc;
-    if (p.out_layout == RT_OUT_TILES) std::copy(tiles.begin(), tiles.end(), out_rgb_sum);
-    else for_each_pixel([&](double *t, size_t f) { out_rgb_sum[f] = t[0]; out_rgb_sum[f + 1] = t[1]; out_rgb_sum[f + 2] = t[2]; });
-    return RT_OK;
-}
-
-int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count, const double *d_gathered, double *d_frame,
-                             void *hip_stream) {
-    if (!d_gathered || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
-        return fail(RT_ERR_INVALID_ARGUMENT, "rt_tiles_to_frame_device: bad argument");
-    const int64_t n = (int64_t)width * height;
-    const int64_t stride = rt_out_size(width, height, RT_OUT_TILES, 0, shard_count);
-    const int32_t tiles_x = (width + RT_TILE_W - 1) / RT_TILE_W;
-    hipLaunchKernelGGL(tiles_to_frame_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, width,
-                       height, tiles_x, shard_count, stride, d_gathered, d_frame);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
-}
-
-int rt_debug_set_tuning(int32_t th_prim, int32_t th_other, int32_t th_shade, int32_t th_box, int32_t use_lds, int32_t th_new) {
-    Tuning &t = tuning();
-    t.forced[0] = th_prim; t.forced[1] = th_other; t.forced[2] = th_shade; t.forced[3] = th_box; t.forced[4] = th_new;
-    if (use_lds >= 0) t.use_lds = use_lds;
-    return RT_OK;
-}
-
-int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max) {
-    Tuning &t = tuning();
-    if (ordered >= 0) t.ordered = ordered;
-    if (leaf_max > 0) t.ordered_options.leaf_max = (uint32_t)leaf_max < OREF_MAX_LEAF ? (uint32_t)leaf_max : OREF_MAX_LEAF;
-    else if (leaf_max == 0) t.ordered_options.leaf_max = OrderedOptions().leaf_max;
-    return RT_OK;
-}
-
-int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) {
-    if (!desc || !io) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: null argument");
-    CompiledScene cs;
-    try {
-        cs = compile_scene(*desc, true);
-        build_ordered(cs, tuning().ordered_options);
-    } catch (const CompileError &e) {
-        return fail(e.status, e.what());
-    } catch (const std::exception &e) {
-        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_ordered_layout: ") + e.what());
-    }
-    io->ordered = cs.ordered ? 1u : 0u;
-    io->root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0u;
-    io->n_steps = (int64_t)cs.oseq.size();
-    if (io->steps) {
-        if (io->cap_steps < io->n_steps) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: steps buffer too small");
-        if (io->n_steps) memcpy(io->steps, cs.oseq.data(), cs.oseq.size() * sizeof(OSeq));
-    }
-    io->n_media = (int64_t)cs.media.size();
-    if (io->media) {
-        if (io->cap_media < io->n_media) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: media buffer too small");
-        for (size_t i = 0; i < cs.media.size(); ++i) io->media[i] = cs.media[i].first_node;
-    }
-    io->stack_entries = cs.ordered_stack;
-    io->n_nodes = (int64_t)cs.onodes.size(); io->n_spheres = (int64_t)cs.spheres.size();
-    io->n_quads = (int64_t)cs.quads.size(); io->n_instances = (int64_t)cs.instances.size();
-    if (io->nodes) {
-        if (io->cap_nodes < io->n_nodes) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: nodes buffer too small");
-        if (io->n_nodes) memcpy(io->nodes, cs.onodes.data(), cs.onodes.size() * sizeof(ONode));
-    }
-    if (io->spheres) {
-        if (io->cap_spheres < io->n_spheres) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: spheres buffer too small");
-        for (size_t i = 0; i < cs.spheres.size(); ++i) {
-            const Sphere &sp = cs.spheres[i];
-            double *o = io->spheres + i * 9;
-            for (int k = 0; k < 3; ++k) { o[k] = sp.center[k]; o[4 + k] = sp.center_vec[k]; }
-            o[3] = sp.radius; o[7] = (double)(sp.seq_moving >> 1); o[8] = (double)(sp.seq_moving & 1u);
-        }
-    }
-    if (io->quads) {
-        if (io->cap_quads < io->n_quads) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: quads buffer too small");
-        for (size_t i = 0; i < cs.quads.size(); ++i) {
-            const Quad &qd = cs.quads[i];
-            double *o = io->quads + i * 10;
-            for (int k = 0; k < 3; ++k) { o[k] = qd.q[k]; o[3 + k] = qd.u[k]; o[6 + k] = qd.v[k]; }
-            o[9] = (double)qd.seq;
-        }
-    }
-    if (io->instances) {
-        if (io->cap_instances < io->n_instances) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: instances buffer too small");
-        for (size_t i = 0; i < cs.instances.size(); ++i) {
-            const Instance &in = cs.instances[i];
-            double *o = io->instances + i * 8;
-            for (int k = 0; k < 3; ++k) o[k] = in.offset[k];
-            o[3] = in.sin_theta; o[4] = in.cos_theta; o[5] = (double)in.parent; o[6] = (double)in.flags; o[7] = (double)in.root;
-        }
-    }
-    return RT_OK;
-}
-
-int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity, int64_t *out_count) {
-    if (!desc || !out_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: null argument");
-    CompiledScene cs;
-    try {
-        cs = compile_scene(*desc, refit != 0);
-    } catch (const CompileError &e) {
-        return fail(e.status, e.what());
-    } catch (const std::exception &e) {
-        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_compiled_nodes: ") + e.what());
-    }
-    *out_count = (int64_t)cs.nodes.size();
-    if (!out_nodes) return RT_OK;
-    if ((int64_t)cs.nodes.size() > capacity) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: buffer too small");
-    for (size_t i = 0; i < cs.nodes.size(); ++i) {
-        const Node &n = cs.nodes[i];
-        const Node32 &m = cs.nodes32[i];
-        rt_debug_node &o = out_nodes[i];
-        for (int k = 0; k < 3; ++k) { o.lo[k] = n.lo[k]; o.hi[k] = n.hi[k]; }
-        o.lo32[0] = m.bx[0]; o.hi32[0] = m.bx[1]; o.lo32[1] = m.by[0]; o.hi32[1] = m.by[1]; o.lo32[2] = m.bz[0]; o.hi32[2] = m.bz[1];
-        o.skip = n.skip; o.kind = n.kind & NODE_KIND_MASK; o.no_bbox = (n.kind & NODE_NO_BBOX) ? 1u : 0u; o.a = n.a; o.b = n.b;
-        o.prim_lo[0] = o.prim_lo[1] = o.prim_lo[2] = INFINITY;
-        o.prim_hi[0] = o.prim_hi[1] = o.prim_hi[2] = -INFINITY;
-        // bound of the record's own primitives (leaves), in the frame the record lives in
-        auto grow = [&](double x, double y, double z) {
-            const double p[3] = {x, y, z};
-            for (int k = 0; k < 3; ++k) { o.prim_lo[k] = std::fmin(o.prim_lo[k], p[k]); o.prim_hi[k] = std::fmax(o.prim_hi[k], p[k]); }
-        };
-        if (o.kind == NK_SPHERES || o.kind == NK_MEDIUM_SPHERE) {
-            const uint32_t first = o.kind == NK_SPHERES ? n.a : cs.media[n.a].first_node, count = o.kind == NK_SPHERES ? n.b : 1u;
-            for (uint32_t q = first; q < first + count; ++q) {
-                const Sphere &sp = cs.spheres[q];
-                for (int e = 0; e < ((sp.seq_moving & 1u) ? 2 : 1); ++e) {
-                    const double c[3] = {sp.center[0] + e * sp.center_vec[0], sp.center[1] + e * sp.center_vec[1], sp.center[2] + e * sp.center_vec[2]};
-                    grow(c[0] - sp.radius, c[1] - sp.radius, c[2] - sp.radius);
-                    grow(c[0] + sp.radius, c[1] + sp.radius, c[2] + sp.radius);
-                }
-            }
-        } else if (o.kind == NK_QUADS) {
-            for (uint32_t q = n.a; q < n.a + n.b; ++q) {
-                const Quad &qd = cs.quads[q];
-                for (int i2 = 0; i2 < 2; ++i2)
-                    for (int j2 = 0; j2 < 2; ++j2)
-                        grow(qd.q[0] + i2 * qd.u[0] + j2 * qd.v[0], qd.q[1] + i2 * qd.u[1] + j2 * qd.v[1], qd.q[2] + i2 * qd.u[2] + j2 * qd.v[2]);
-            }
-        }
-    }
-    return RT_OK;
-}
-
-int rt_debug_stage_profile(uint64_t out[24]) {
-    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
-    std::lock_guard<std::mutex> lock(g_stage_profile_mu);
-    for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) out[q] = g_stage_profile[q];
-    return RT_OK;
-}
-
-int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *out_exact_hit,
-                       uint8_t *out_f32_hit, int device) {
-    if (n <= 0 || !rays || !boxes || !out_exact_hit || !out_f32_hit) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_box_tests: bad argument");
-    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_box_tests: no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    double *dr = nullptr, *db = nullptr;
-    uint8_t *de = nullptr, *df = nullptr;
-    const size_t bytes = (size_t)n * 6 * sizeof(double);
-    int rc = RT_OK;
-    do {
-        if (hipMalloc((void **)&dr, bytes) != hipSuccess || hipMalloc((void **)&db, bytes) != hipSuccess ||
-            hipMalloc((void **)&de, (size_t)n) != hipSuccess || hipMalloc((void **)&df, (size_t)n) != hipSuccess) {
-            rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_box_tests: hipMalloc failed"); break;
-        }
-        if (hipMemcpy(dr, rays, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, boxes, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-            rc = fail(RT_ERR_HIP, "rt_debug_box_tests: upload failed"); break;
-        }
-        hipLaunchKernelGGL(debug_box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, dr, db, tmin, tmax, de, df);
-        if (hipMemcpy(out_exact_hit, de, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(out_f32_hit, df, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) {
-            rc = fail(RT_ERR_HIP, "rt_debug_box_tests: download failed"); break;
-        }
-    } while (0);
-    (void)hipFree(dr); (void)hipFree(db); (void)hipFree(de); (void)hipFree(df);
-    return rc;
-}
-
-int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device) {
-    if (n <= 0 || !a || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_eval: bad argument");
-    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_eval: no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    double *da = nullptr, *db = nullptr, *dout = nullptr;
-    const size_t bytes = (size_t)n * sizeof(double);
-    int rc = RT_OK;
-    do {
-        if (hipMalloc((void **)&da, bytes) != hipSuccess || hipMalloc((void **)&dout, bytes) != hipSuccess ||
-            (b && hipMalloc((void **)&db, bytes) != hipSuccess)) { rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_eval: hipMalloc failed"); break; }
-        if (hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-            (b && hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) != hipSuccess)) { rc = fail(RT_ERR_HIP, "rt_debug_eval: upload failed"); break; }
-        hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, da, db, dout);
-        hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { rc = fail(RT_ERR_HIP, std::string("rt_debug_eval: ") + hipGetErrorString(e)); break; }
-    } while (0);
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
-    return rc;
-}
-
-int rt_resolve_rgb8_device(int32_t width, int32_t height, int32_t spp, const double *d_frame_sum, uint8_t *d_rgb8, void *hip_stream) {
-    if (!d_frame_sum || !d_rgb8 || width <= 0 || height <= 0 || spp <= 0)
-        return fail(RT_ERR_INVALID_ARGUMENT, "rt_resolve_rgb8_device: bad argument");
-    const int64_t n = (int64_t)width * height * 3;
-    hipLaunchKernelGGL(resolve_rgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, n,
-                       1.0 / (double)spp, d_frame_sum, d_rgb8);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
-}
-
-} // extern "C"
+} // namespace rtk

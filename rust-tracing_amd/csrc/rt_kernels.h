@@ -1,0 +1,117 @@
+// rt_kernels.h — the seam between the device code (rt_kernel.hip) and the host side of librt_amd (rt_api.cpp, rt_debug.cpp):
+// the kernels' parameter block, the feature bits a kernel instantiation is compiled for, and the launch entry points.
+#pragma once
+#include "rt_amd.h"
+#include "rt_layout.h"
+
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <cstdint>
+
+namespace rtk {
+using namespace rtd;
+
+struct DMaterial { // 64 bytes
+    uint32_t kind;
+    uint32_t texture;
+    uint32_t needs_uv; // the texture below reads (u, v): only ImageTexture does (src/texture.rs:83)
+    uint32_t solid;    // the texture is a SolidColor: its colour is copied into `albedo` (one dependent load fewer per hit)
+    double albedo[3];  // Metal's albedo, or the SolidColor's colour
+    double fuzz;
+    double ir;
+    double _pad2;
+};
+static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
+
+struct KParams {
+    const Node32 *nodes;
+    const Sphere *spheres;
+    const Quad *quads;
+    const Instance *insts;
+    const Medium *media;
+    const DMaterial *mats;
+    const rt_texture *texs;
+    const rt_perlin *perlins;
+    const ImageRef *images;
+    const uint8_t *texels;
+    const double *srgb_lut;
+    double *out;
+    double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
+    double *att_stack;              // [max_depth + 1][n_threads][3]: attenuations of the current path
+    uint32_t *job_counter;
+    unsigned long long *counters;   // rt_counters as 10 u64, then per profile slot (9): rounds, active lanes, cycles; or null
+    rt_camera cam;
+    uint64_t seed_mixed;            // mix64(seed + gamma)
+    uint32_t n_nodes;
+    uint32_t n_threads;
+    int32_t sample_begin;           // first sample of this launch
+    uint32_t n_samples;             // samples per pixel in this launch
+    uint32_t n_jobs;                // n_local_tiles * n_samples * 64
+    uint32_t jobs_per_grab;
+    double inv_n_samples, inv_tiles_x; // 1 / n_samples, 1 / tiles_x (job decode)
+    int32_t max_depth, accumulate;
+    int32_t shard_index, shard_count, out_layout;
+    int32_t tiles_x;
+    uint32_t n_local_tiles;
+    uint32_t th_prim, th_other, th_shade, th_new; // scheduler thresholds, in 64ths of the live lanes
+    uint32_t th_box;                // the box loop keeps running while this many 64ths of the live lanes are in it
+    // LDS-resident scene (SCENE_IN_LDS kernels): image to copy in, and where its parts start (bytes)
+    const uint4 *lds_image;
+    uint32_t lds_image_bytes;
+    uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
+    double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
+    // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
+    const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
+    const OSeq *oseq;               // the world frame's sequence of trees and media (rt_layout.h)
+    float box_extent;               // the largest |coordinate| of any box of the ordered layout (box_pair_f32's B)
+    const uint4 *aux_image;         // AUX kernels: materials | textures | frames | media | Perlin tables, to copy into the LDS
+    uint32_t aux_bytes, lds_aux_off, aux_off_mats, aux_off_texs, aux_off_insts, aux_off_media, aux_off_perlins;
+    uint32_t n_oseq;
+    uint32_t o_root;
+    uint32_t lds_stack_off;
+    uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)
+    uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
+};
+
+// What a scene can contain.  A kernel instantiated without a feature has that code compiled out, which matters for
+// more than its size: the register allocation of the whole kernel is set by its hungriest path.
+enum Feature : uint32_t {
+    F_SPHERES = 1u,  // Sphere leaves
+    F_QUADS = 2u,    // Quad leaves
+    F_FRAMES = 4u,   // Translate / RotateY
+    F_MEDIA = 8u,    // ConstantMedium
+    F_TEXTURES = 16u // Checker / Image / Noise textures (without it every texture is a SolidColor)
+};
+constexpr uint32_t F_ALL = 31u;
+
+constexpr uint32_t PROF_SLOTS = 8;       // COUNT kernels: profile slots per wave (6 stages + 2 parts of the shade stage)
+// Jobs a wave reserves at a time: a multiple of 64 (one sample-row of an 8x8 tile, so the lanes a wave starts together
+// trace neighbouring pixels).  Large grabs mean few atomics; small ones a short tail (the last grab of the slowest wave
+// is all that is left running at the end): launch_render picks the size so that every wave gets at least ~32 grabs.
+constexpr uint32_t MAX_JOBS_PER_GRAB = 1024, MIN_JOBS_PER_GRAB = 64;
+
+constexpr int GLOBAL_THREADS = 256;             // scene gathered from global memory: 256-thread blocks
+#ifndef RT_LDS_THREADS
+#define RT_LDS_THREADS 1024 // 16 waves = 4 per SIMD (tools/tune.py: 512 -> 1381, 768 -> 1774, 1024 -> 1921 Msamples/s on C2 at 48 spp)
+#endif
+constexpr int LDS_THREADS = RT_LDS_THREADS;     // scene in LDS: one 16-wave workgroup per CU shares the copy
+constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
+
+// The kernel instantiations that exist: the general one (every feature) at each LDS level, plus specialised
+// ones for scenes that fit the LDS entirely and use a subset of the features (BASELINE configs 1/2 and 3).
+constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
+constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
+uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
+const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux);
+
+// launches of the small kernels (all asynchronous on `stream`; errors through hipGetLastError)
+void launch_sum_samples(const KParams &K, unsigned grid, hipStream_t stream);
+void launch_tiles_to_frame(int32_t w, int32_t h, int32_t tiles_x, int32_t shard_count, int64_t shard_stride, const double *gathered,
+                           double *frame, hipStream_t stream);
+void launch_tiles_to_frame_rgb8(int32_t w, int32_t h, int32_t tiles_x, int32_t shard_count, int64_t shard_stride, const uint8_t *gathered,
+                                uint8_t *frame, hipStream_t stream);
+void launch_resolve_rgb8(int64_t n_values, double inv_spp, const double *sum, uint8_t *rgb, hipStream_t stream);
+void launch_debug_box(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *exact_hit, uint8_t *f32_hit);
+void launch_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out);
+
+} // namespace rtk

@@ -18,6 +18,8 @@ CASES = {
     "c3_cornell_box_64x64_16spp_d50": dict(scene=6, width=64, spp=16, depth=50),
     "cornell_smoke_64x64_16spp": dict(scene=7, width=64, spp=16, depth=8),
     "c4_final_scene_64x64_8spp_d40": dict(scene=8, width=64, spp=8, depth=40, earth_image=EARTH_SMALL),
+    # BASELINE.json configs[4] (the 8-GPU case: final_scene at depth 50) at a size the oracle can check
+    "c5_final_scene_64x64_8spp_d50": dict(scene=8, width=64, spp=8, depth=50, earth_image=EARTH_SMALL),
     # ragged: neither dimension a multiple of the 8x8 tile
     "ragged_cornell_37x37_4spp": dict(scene=6, width=37, spp=4, depth=8),
     "ragged_random_balls_53x29_4spp": dict(scene=0, width=53, spp=4, depth=10),

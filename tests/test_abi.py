@@ -26,6 +26,10 @@ def test_librt_amd_exports_everything_rt_amd_h_declares(rt):
     have = exported(rt.LIB_DIR / "librt_amd.so")
     assert not [n for n in names if n not in have]
     assert sorted(rt.RT_AMD_SYMBOLS) == names, "python binding table out of sync with rt_amd.h"
+    assert not [n for n in names if n.startswith("rt_debug")], "test hooks belong in rt_amd_debug.h"
+    debug_names = declared("rt_amd_debug.h")
+    assert not [n for n in debug_names if n not in have]
+    assert sorted(rt.RT_AMD_DEBUG_SYMBOLS) == debug_names, "python binding table out of sync with rt_amd_debug.h"
     lib = rt.amd_lib()  # binds every symbol; loading must not need a GPU
     assert lib.rt_version().startswith(b"rt_amd")
     assert lib.rt_device_count() >= 0
@@ -66,7 +70,7 @@ def test_ctypes_structs_match_the_c_layout(rt, tmp_path):
                "rt_bvh": rt.Bvh, "rt_constant_medium": rt.ConstantMedium, "rt_material": rt.Material,
                "rt_texture": rt.Texture, "rt_perlin": rt.Perlin, "rt_image": rt.Image, "rt_scene_desc": rt.SceneDesc,
                "rt_camera": rt.Camera, "rt_render_params": rt.RenderParams, "rt_counters": rt.Counters,
-               "rt_scene_stats": rt.SceneStats, "rth_scene_options": rt.SceneOptions}
+               "rt_scene_stats": rt.SceneStats, "rt_scene_options": rt.SceneCreateOptions, "rth_scene_options": rt.SceneOptions}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_host.h"', "int main(void){"]
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

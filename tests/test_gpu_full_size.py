@@ -104,3 +104,29 @@ def test_c4_final_scene_800x800_depth40(rt, gpu):
     assert digest(part) == ref
     f = whole.cpu().numpy() / 400.0
     assert np.isfinite(f).all() and f.min() >= 0.0 and 0.05 < f.mean() < 2.0
+
+
+def test_c5_final_scene_1600x1600_depth50_in_8_shards(rt, gpu):
+    """BASELINE.json configs[4]: final_scene 1600x1600 at depth 50, cut into the 8 tile shards of the 8-GPU run; 48 of the
+    10000 spp keep it to seconds.  The sample buffer is capped at 64 MiB for this scene, so the whole frame (61 MB per sample
+    row) runs one sample per launch and every shard (7.7 MB per row) fills and drains its buffer six times: chunked launches,
+    chained sample ranges and the shard layout all have to agree on one frame."""
+    hs = rt.HostScene(8, scene_seed=1, width=1600, aspect=1.0, spp=48, depth=50, earth_image="synthetic:6400x3200")
+    assert (hs.width, hs.height, hs.camera.max_depth) == (1600, 1600, 50)
+    ds = rt.DeviceScene(hs)                                     # default sample buffer (2 GiB): 34 spp per launch
+    small = rt.DeviceScene(hs, sample_buffer_bytes=64 << 20)    # 1 spp per launch whole, 8 spp per launch per shard
+    whole = render(rt, ds, hs)
+    ref = digest(whole)
+    assert digest(render(rt, small, hs)) == ref
+    assert digest(reassemble(rt, small, hs, 8)) == ref
+    # chained ranges on top of chunked launches: [0, 5) [5, 31) [31, 48)
+    part = render(rt, small, hs, sample_end=5)
+    stream = torch.cuda.current_stream().cuda_stream
+    small.render_device(rt.render_params(seed=1, sample_begin=5, sample_end=31, accumulate=True), part.data_ptr(), stream)
+    small.render_device(rt.render_params(seed=1, sample_begin=31, accumulate=True), part.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert digest(part) == ref
+    # the reference-order walk renders the same frame (other kernel, other layout)
+    assert digest(render(rt, rt.DeviceScene(hs, walk=rt.RT_WALK_REFERENCE_ORDER), hs)) == ref
+    f = whole.cpu().numpy() / 48.0
+    assert np.isfinite(f).all() and f.min() >= 0.0 and 0.05 < f.mean() < 2.0

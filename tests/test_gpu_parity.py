@@ -253,6 +253,15 @@ def test_device_output_stage_matches_host(rt, gpu):
     rt.resolve_rgb8_device(hs.width, hs.height, 16, d.data_ptr(), rgb.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     host = rt.resolve_rgb8_host(hs.width, hs.height, 16, sums).reshape(-1)
-    diff = np.abs(rgb.cpu().numpy().astype(int) - host.astype(int))
-    # device pow is OCML's, host pow is libm's: a value within 1 ulp of a quantisation step may land either side
-    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    # one algorithm on both sides (rt_shared_math.h): byte for byte
+    assert np.array_equal(rgb.cpu().numpy(), host)
+    # ... also on values chosen to sit on and next to every quantisation step, and on the special cases
+    steps = (np.arange(1, 256) / 256.0) ** 2.2
+    x = np.concatenate([steps, np.nextafter(steps, 0), np.nextafter(steps, 2), [0.0, -0.0, -1.0, np.inf, np.nan, 1e-300, 5e-324, 1e300],
+                        np.random.default_rng(3).uniform(0, 1.5, 100000)])
+    x = np.resize(x, (x.size // 3) * 3)
+    dx = torch.from_numpy(x).cuda()
+    out = torch.zeros(x.size, dtype=torch.uint8, device="cuda")
+    rt.resolve_rgb8_values_device(x.size, 1, dx.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), rt.resolve_rgb8_host(x.size // 3, 1, 1, x).reshape(-1))

@@ -138,6 +138,13 @@ def test_output_stage(rt, tmp_path):
     assert rgb[1].tolist() == [int(256 * 0.5 ** (1 / 2.2)), int(256 * 0.25 ** (1 / 2.2)), int(256 * 1e-9 ** (1 / 2.2))]
     assert rgb[2].tolist() == [0, 0, 255]
     assert rgb[3].tolist()[1:] == [int(256 * 0.2 ** (1 / 2.2)), 217]
+    # the fixed-algorithm x^(1/2.2) (rt_shared_math.h, shared with the device) quantises like libm's pow
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(0, 1.2, 300000), 10.0 ** rng.uniform(-12, 3, 100000)])
+    x = np.resize(x, (x.size // 3) * 3)
+    got = rt.resolve_rgb8_host(x.size // 3, 1, 1, x).reshape(-1)
+    want = (256.0 * np.clip(x ** (1 / 2.2), 0.0, 0.999)).astype(np.uint8)
+    assert (got != want).sum() == 0  # (only a value within an ulp or two of a quantisation step could land on the other side)
     # PNG writer round trip
     from PIL import Image
     img = np.random.default_rng(0).integers(0, 256, (37, 53, 3), dtype=np.uint8)

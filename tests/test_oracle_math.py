@@ -61,7 +61,12 @@ def test_rng_definition_and_statistics(oracle):
     for seed, pixel, sample, n in [(1, 0, 0, 0), (20231003, 959999, 499, 13), (mask, 2 ** 31, 9999, 1000)]:
         key = mix64(mix64((seed + G) & mask) ^ ((pixel << 32) | sample))
         assert L.orc_rng_key(seed, pixel, sample) == key                 # rt_amd.h "RNG", line by line
-        x = mix64((key + (n + 1) * G) & mask)
+        sx, sy = key, mix64((key + G) & mask)                            # RomuDuoJr started from the key
+        for _ in range(n + 1):
+            x = sx
+            sx = (0xD3833E804F4C574B * sy) & mask
+            sy = (sy - x) & mask
+            sy = ((sy << 27) | (sy >> 37)) & mask
         assert L.orc_rng_draw(key, n) == x
         assert L.orc_kat_random(key, n) == (x >> 11) * 2.0 ** -53
         v12 = np.array([(x >> 12) | 0x3FF0000000000000], dtype=np.uint64).view(np.float64)[0]
