@@ -39,7 +39,6 @@ SCENE_SEED = 1
 RENDER_SEED = 1
 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (256 CU x 64 FMA/clk x 2 x 2.4 GHz); SURVEY.md Appendix B
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
 def algorithmic_work_per_sample(cnt):
@@ -63,6 +62,9 @@ def main():
     ap.add_argument("--bvh", default="reference", choices=["reference", "sah"])
     ap.add_argument("--spp", type=int, default=0, help="override spp (smoke runs only: the JSON then names the reduced config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
+                    help="N > 1: the frame-end gather through torch.distributed (RCCL behind it) or through the C ABI's own "
+                         "rt_gather_tiles_device (RCCL loaded by librt_amd; the unique id travels over torch.distributed)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 control flow on ONE GPU (all ranks share device 0, the gather goes "
                          "through host memory); not a measurement")
@@ -116,6 +118,12 @@ def main():
     else:
         params = rt.render_params(seed=RENDER_SEED)
 
+    comm = None
+    if world > 1 and args.gather == "native" and not rehearsal:
+        ids = [rt.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = rt.Comm.create(ids[0], rank, world, local_rank)
+
     kernel_ms = []
 
     def step(timed):
@@ -137,6 +145,8 @@ def main():
                 rtdist.gather_tiles(h_tiles, h_all, rank, world)
                 if rank == 0:
                     gathered.copy_(h_all)
+            elif comm is not None:
+                comm.gather_tiles(w, h, 8, tiles.data_ptr(), gathered.data_ptr() if rank == 0 else 0, 0, stream.cuda_stream)
             else:
                 rtdist.gather_tiles(tiles, gathered, rank, world)
             if rank == 0:
@@ -172,9 +182,7 @@ def main():
         scratch = torch.zeros(w * h * 3, dtype=torch.float64, device=dev)
         cnt_params = rt.render_params(seed=RENDER_SEED, sample_end=cnt_spp)
         executed = scene.render_device_counted(cnt_params, scratch.data_ptr(), stream.cuda_stream)
-        rt.amd_lib().rt_debug_set_traversal(0, -1)
-        ref_walk = rt.DeviceScene(hs, device=local_rank)
-        rt.amd_lib().rt_debug_set_traversal(1, -1)
+        ref_walk = rt.DeviceScene(hs, device=local_rank, walk=rt.RT_WALK_REFERENCE_ORDER)
         cnt = ref_walk.render_device_counted(cnt_params, scratch.data_ptr(), stream.cuda_stream)
         del ref_walk
         flops_ps, bytes_ps, per = algorithmic_work_per_sample(cnt)
@@ -182,19 +190,24 @@ def main():
         samples_per_launch = w * h * spp / world
         k_ms = sum(kernel_ms) / len(kernel_ms)
         tflops = flops_ps * samples_per_launch / (k_ms * 1e-3) / 1e12
-        gbs = bytes_ps * samples_per_launch / (k_ms * 1e-3) / 1e9
         host_frame = frame.cpu().numpy()
         assert np.isfinite(host_frame).all() and host_frame.max() > 0.0, "rendered frame is empty or not finite"
 
         total_samples = float(w) * h * spp * args.steps
         value = total_samples / elapsed / 1e6
-        traffic = None
+        # HBM bytes per launch cannot be counted from inside this process: they come from the rocprofv3 PMC passes of
+        # tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction), committed per workload in
+        # profiles/hbm_traffic.json together with the tag of the build they were measured on
+        traffic, traffic_source = None, "no PMC pass of this workload is committed under profiles/"
         tp = ROOT / "profiles" / "hbm_traffic.json"
-        if tp.exists():
+        if tp.exists() and world == 1 and args.spp == 0:
             try:
-                traffic = json.loads(tp.read_text()).get(args.workload, {}).get("bytes_per_launch")
+                entry = json.loads(tp.read_text()).get(args.workload)
+                if entry:
+                    traffic = entry.get("bytes_per_launch")
+                    traffic_source = f"profiles/hbm_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build {entry.get('tag')}"
             except Exception:
-                traffic = None
+                pass
         result = {
             "metric": "Msamples/sec (pixels x spp / render seconds)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,16 +218,15 @@ def main():
                        "parallelism": (f"tiles{world}" if world > 1 else "single") + (" [gloo rehearsal on one GPU]" if rehearsal else "")},
             "roofline": {
                 "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
-                "kernel": "path_kernel<false>", "kernel_ms": round(k_ms, 3),
+                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "path_kernel (render megakernel)", "kernel_ms": round(k_ms, 3),
                 "algorithmic_flops_per_sample": round(flops_ps, 1), "algorithmic_bytes_per_sample": round(bytes_ps, 1),
                 "events_per_sample": {k: round(v, 3) for k, v in per.items() if k != "samples"},
                 "executed_events_per_sample": {k: round(v, 3) for k, v in executed_per.items() if k != "samples"},
                 "walk": "own trees, nearest child first" if scene.stats()["ordered"] else "reference tree, reference order",
-                "hbm": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 5),
-                        "note": "algorithmic bytes are scene records, served from the LDS / L2 copy of the scene, not from "
-                                "HBM: this is not the binding resource (DESIGN.md Roofline); `traffic` is the measured HBM bytes"},
+                "note": "bound: VALU issue under divergence (no MFMA: no dense contraction; not HBM: the scene is LDS / L2 "
+                        "resident and `traffic` is a few per cent of 8 TB/s x kernel time); algorithmic_bytes are scene-record "
+                        "bytes of the reference walk, listed for SURVEY 8(d), not an HBM figure",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -227,10 +239,17 @@ def main():
             t1 = time.perf_counter()
             oracle_lib.render(hs, rt.render_params(seed=RENDER_SEED, sample_end=base_spp), threads=cores)
             dt = time.perf_counter() - t1
+            # BASELINE.md's second CPU row: the same restatement with the tightened box test (flat / tight mode) — separates
+            # what the algorithmic fix buys on a CPU from what the GPU buys
+            t1 = time.perf_counter()
+            oracle_lib.render(hs, rt.render_params(seed=RENDER_SEED, sample_end=base_spp), threads=cores, aabb_mode=oracle_lib.ORC_AABB_TIGHT)
+            dt_tight = time.perf_counter() - t1
             result["cpu_baseline"] = {
                 "value": round(w * h * base_spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                 "sample": f"{w}x{h}, first {base_spp} of {spp} spp (cost is linear in spp), "
-                          f"reference-faithful mode (recursive, untightened box test), {dt:.1f} s"}
+                          f"reference-faithful mode (recursive, untightened box test), {dt:.1f} s",
+                "tight_box_test": {"value": round(w * h * base_spp / dt_tight / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+                                   "sample": f"same sample, narrowing slab test (same image bit for bit), {dt_tight:.1f} s"}}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -73,9 +73,10 @@ int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
 
 /* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
  * (box, sphere, quad, other, shade, new-job): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)
- * summed over waves; then two parts of the shade stage, cycles only (hit rebuild, unit-sphere rejection sampling — the shade
- * slot itself keeps the remainder). */
-int rt_debug_stage_profile(uint64_t out[24]);
+ * summed over waves; then six parts of the shade / path-end rounds, cycles only (hit rebuild, unit-sphere rejection sampling,
+ * texture, material + next ray, attenuation products + sample store, job hand-out + camera ray — the stage slots keep the
+ * remainder: scheduling and the start of the next query). */
+int rt_debug_stage_profile(uint64_t out[36]);
 
 /* Tuning hook: the wave scheduler's knobs (DESIGN.md "Scheduler").  A deferred stage runs once th/64 of a wave's
  * live lanes wait for it (th_new: the path-end / next-job stage); the box loop keeps running while th_box/64 of them are in

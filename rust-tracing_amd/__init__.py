@@ -297,10 +297,11 @@ def debug_ordered_layout(host_scene) -> dict:
 
 def debug_stage_profile() -> dict:
     """rt_debug_stage_profile: per stage {rounds, lanes (mean active per round), cycles} of the last counted render."""
-    buf = (C.c_uint64 * 24)()
+    buf = (C.c_uint64 * 36)()
     _check(amd_lib().rt_debug_stage_profile(buf), "rt_debug_stage_profile")
     out = {}
-    for i, name in enumerate(("box", "sphere", "quad", "other", "shade", "newjob", "shade.rebuild", "shade.sample")):
+    for i, name in enumerate(("box", "sphere", "quad", "other", "shade", "newjob", "shade.rebuild", "shade.sample", "shade.texture",
+                              "shade.material", "end.products", "end.newjob")):
         rounds, lanes, cycles = int(buf[3 * i]), int(buf[3 * i + 1]), int(buf[3 * i + 2])
         out[name] = {"rounds": rounds, "mean_active_lanes": lanes / rounds if rounds else 0.0, "cycles": cycles}
     return out

@@ -23,7 +23,7 @@ int fail(int status, const std::string &msg) {
 Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
     if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
@@ -167,7 +167,8 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     // persistent grid: every resident wave pulls jobs until none are left
     int64_t grid = (int64_t)scene->n_cus * bpc;
     const int64_t waves_per_block = threads / 64;
-    const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_GRAB * waves_per_block - 1) / (MIN_JOBS_PER_GRAB * waves_per_block);
+    // (a small frame gets a smaller grid: a wave with fewer than MIN_JOBS_PER_WAVE jobs costs more to start than it adds)
+    const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_WAVE * waves_per_block - 1) / (MIN_JOBS_PER_WAVE * waves_per_block);
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
     const uint32_t n_threads = (uint32_t)(grid * threads);
@@ -223,10 +224,10 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             chunk = (int64_t)(w.sample_bytes / (size_t)bytes_per_sample_row);
         }
         if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
-        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, 40 * sizeof(unsigned long long)));
+        if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
         ws = w;
     }
-    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, 40 * sizeof(unsigned long long), stream));
+    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
 
     KParams K{};
     K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
@@ -279,6 +280,8 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             if (per_grab > MAX_JOBS_PER_GRAB) per_grab = MAX_JOBS_PER_GRAB;
             if (per_grab < MIN_JOBS_PER_GRAB) per_grab = MIN_JOBS_PER_GRAB;
             K.jobs_per_grab = (uint32_t)per_grab;
+            // (RT_GRAB_TAPER=0 switches the taper off: every grab is jobs_per_grab)
+            K.grab_taper = tn.grab_taper > 0 ? 1.0f / (float)(waves * tn.grab_taper) : 1.0f; // (default 8, tools/sweep_grabs.sh)
         }
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
         HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
@@ -292,7 +295,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
 
     if (counted) {
-        unsigned long long host[40];
+        unsigned long long host[COUNTER_WORDS];
         HIP_TRY(hipMemcpyAsync(host, ws.counters, sizeof host, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         {

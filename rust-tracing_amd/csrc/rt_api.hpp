@@ -53,6 +53,7 @@ struct Tuning {
     int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
+    int grab_taper = 8;    // guided hand-out: a grab takes at most 1 / (waves x this) of the jobs left (RT_GRAB_TAPER; 0: off; tools/sweep_grabs.sh)
     OrderedOptions ordered_options;
     size_t sample_buffer_bytes = (size_t)2 << 30; // per-(scene, stream) sample buffer at most (halved on out-of-memory)
     Tuning();

@@ -138,7 +138,7 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
     return RT_OK;
 }
 
-int rt_debug_stage_profile(uint64_t out[24]) {
+int rt_debug_stage_profile(uint64_t out[36]) {
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_stage_profile: null argument");
     std::lock_guard<std::mutex> lock(g_stage_profile_mu);
     for (uint32_t q = 0; q < PROF_SLOTS * 3u; ++q) out[q] = g_stage_profile[q];

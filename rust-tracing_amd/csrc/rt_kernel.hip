@@ -11,152 +11,12 @@
 //
 // There is no dense contraction anywhere on this path: no MFMA.  The bound is VALU issue under divergence (DESIGN.md
 // "Roofline").  Host side: rt_api.cpp (C ABI, scene upload, launches), rt_debug.cpp (test hooks), rt_gather.cpp (RCCL).
-#include "rt_kernels.h"
-#include "rt_amd_debug.h"
-#include "rt_device_math.h"
-
-#include <hip/hip_runtime.h>
-
-using namespace rtd;
-using namespace rtk;
+#include "rt_device_scene.h"
 
 // =====================================================================================================
 // Device side
 // =====================================================================================================
 namespace {
-
-struct Counts {
-    uint32_t samples, rays, node_visits, sphere_tests, quad_tests, medium_visits, rng_draws, noise_evals,
-        image_lookups, instance_enters;
-};
-
-RT_DEV V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
-RT_DEV V3 from(const rt_vec3 &a) { return V3{a.x, a.y, a.z}; }
-
-// ---- frame changes (Translate::hit then RotateY::hit, src/hittable.rs:96-106,:159-188) -------------------
-RT_DEV void apply_instance(const Instance &in, V3 &o, V3 &d) {
-    // all fields are read up front (one memory round trip, not one per `if (flags & ...)`)
-    const uint32_t flags = in.flags;
-    const V3 offset = ld3(in.offset);
-    const double c = in.cos_theta, s = in.sin_theta;
-    if (flags & INST_TRANSLATE) o = o - offset;
-    if (flags & INST_ROTATE) {
-        const double ox = c * o.x - s * o.z, oz = s * o.x + c * o.z;
-        const double dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
-        o.x = ox; o.z = oz; d.x = dx; d.z = dz;
-    }
-}
-// world ray -> the frame of instance `inst` (outermost ancestor first); inst < 0: world frame
-RT_DEV void ray_to_frame(const Instance *insts, int32_t inst, V3 &o, V3 &d) {
-    if (inst < 0) return;
-    const uint32_t depth = insts[inst].depth;
-    for (uint32_t lv = 0; lv <= depth; ++lv) {
-        int32_t a = inst;
-        for (uint32_t k = depth; k > lv; --k) a = insts[a].parent;
-        apply_instance(insts[a], o, d);
-    }
-}
-// hit point and normal from the frame of `inst` back to the world (innermost first):
-// RotateY's output step (src/hittable.rs:173-182) then Translate's (src/hittable.rs:101)
-RT_DEV void hit_to_world(const Instance *insts, int32_t inst, V3 &p, V3 &n) {
-    while (inst >= 0) {
-        const Instance &in = insts[inst];
-        if (in.flags & INST_ROTATE) {
-            const double c = in.cos_theta, s = in.sin_theta;
-            const double px = c * p.x + s * p.z, pz = -s * p.x + c * p.z;
-            const double nx = c * n.x + s * n.z, nz = -s * n.x + c * n.z;
-            p.x = px; p.z = pz; n.x = nx; n.z = nz;
-        }
-        if (in.flags & INST_TRANSLATE) p = p + ld3(in.offset);
-        inst = in.parent;
-    }
-}
-
-// ---- random vectors (src/vec3.rs:54-88) ------------------------------------------------------------------
-template <bool COUNT> RT_DEV V3 random_in_unit_sphere(Rng &rng, Counts &cn) {
-    for (;;) {
-        const double x = rng.range(-1.0, 1.0);
-        const double y = rng.range(-1.0, 1.0);
-        const double z = rng.range(-1.0, 1.0);
-        if (COUNT) cn.rng_draws += 3;
-        const V3 p = v3(x, y, z);
-        if (len2(p) < 1.0) return p;
-    }
-}
-template <bool COUNT> RT_DEV V3 random_unit_vector(Rng &rng, Counts &cn) {
-    return normalize(random_in_unit_sphere<COUNT>(rng, cn));
-}
-
-// ---- Perlin (src/perlin.rs:27-64,:81-100) ----------------------------------------------------------------
-// Rare and register-hungry: kept as rolled loops (one corner of the lattice cell per iteration) so that its
-// temporaries do not inflate the register allocation of the whole kernel.
-RT_DEV double perlin_turbulence(const rt_perlin *pn, V3 p, int depth) {
-    double acc = 0.0;
-    double wgt = 1.0;
-#pragma unroll 1
-    for (int dpt = 0; dpt < depth; ++dpt) {
-        // Perlin::noise (src/perlin.rs:27-50)
-        const int32_t i = f64_as_i32(__builtin_floor(p.x));
-        const int32_t j = f64_as_i32(__builtin_floor(p.y));
-        const int32_t k = f64_as_i32(__builtin_floor(p.z));
-        const double u = p.x - (double)i;
-        const double v = p.y - (double)j;
-        const double w = p.z - (double)k;
-        // trilinear_interpolation (src/perlin.rs:81-100)
-        const double uu = u * u * (3.0 - 2.0 * u);
-        const double vv = v * v * (3.0 - 2.0 * v);
-        const double ww = w * w * (3.0 - 2.0 * w);
-        double noise = 0.0;
-#pragma unroll 1
-        for (int corner = 0; corner < 8; ++corner) { // (di, dj, dk) in the reference's loop order: dk fastest
-            const int di = corner >> 2, dj = (corner >> 1) & 1, dk = corner & 1;
-            const int32_t idx = pn->perm_x[(uint32_t)(i + di) & 255u] ^ pn->perm_y[(uint32_t)(j + dj) & 255u] ^
-                                pn->perm_z[(uint32_t)(k + dk) & 255u];
-            const V3 c = from(pn->ranvec[idx]);
-            // `i as FP * uu + (1 - i) as FP * (1 - uu)` is exactly uu (i = 1) or 1 - uu (i = 0)
-            const double fi = di ? uu : 1.0 - uu;
-            const double fj = dj ? vv : 1.0 - vv;
-            const double fk = dk ? ww : 1.0 - ww;
-            const V3 weight_v = v3(u - (double)di, v - (double)dj, w - (double)dk);
-            noise += fi * fj * fk * dot(c, weight_v);
-        }
-        acc += wgt * noise;
-        wgt *= 0.5;
-        p = p * 2.0;
-    }
-    return __builtin_fabs(acc);
-}
-
-RT_DEV double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
-
-// ---- Texture::value (src/texture.rs) ---------------------------------------------------------------------
-template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, const rt_texture *texs, const rt_perlin *perlins, uint32_t tex, double u, double v, V3 p,
-                                              Counts &cn) {
-    const rt_texture *t = &texs[tex];
-    while (t->kind == RT_TEXTURE_CHECKER) { // src/texture.rs:59-69
-        const int32_t x = f64_as_i32(__builtin_floor(t->inv_scale * p.x));
-        const int32_t y = f64_as_i32(__builtin_floor(t->inv_scale * p.y));
-        const int32_t z = f64_as_i32(__builtin_floor(t->inv_scale * p.z));
-        const int32_t s = (int32_t)((uint32_t)x + (uint32_t)y + (uint32_t)z);
-        t = &texs[(s % 2 == 0) ? t->even : t->odd];
-    }
-    if (t->kind == RT_TEXTURE_SOLID) return from(t->color); // src/texture.rs:32-36
-    if (t->kind == RT_TEXTURE_IMAGE) {                      // src/texture.rs:82-92
-        if (COUNT) cn.image_lookups++;
-        const ImageRef im = P.images[t->image];
-        const double uc = clamp01(u);
-        const double vc = 1.0 - clamp01(v);
-        const uint32_t i = f64_as_u32(uc * (double)(im.width - 1u));
-        const uint32_t j = f64_as_u32(vc * (double)(im.height - 1u));
-        const uint8_t *px = P.texels + im.offset + ((size_t)j * im.width + i) * 3u;
-        return v3(P.srgb_lut[px[0]], P.srgb_lut[px[1]], P.srgb_lut[px[2]]);
-    }
-    // RT_TEXTURE_NOISE, src/texture.rs:107-110
-    if (COUNT) cn.noise_evals++;
-    const double turb = perlin_turbulence(&perlins[t->perlin], p, 7);
-    const double s = rt_sin(t->scale * p.z + 10.0 * turb) * 0.5 + 0.5;
-    return v3(s, s, s);
-}
 
 // ---- the render kernel: a wave-scheduled stage machine ----------------------------------------------------
 //
@@ -179,214 +39,6 @@ enum Terminal : uint32_t { TERM_BACKGROUND = 0, TERM_ONE = 1, TERM_ZERO = 2, TER
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for (tools/tune.py: 3 beats 2 and 4)
 #endif
-
-// What one box-stage round needs of a record
-struct NodeData {
-    float lo[3], hi[3];
-    uint32_t skip, packed;
-};
-
-// SCENE_IN_LDS: the node, sphere and quad tables are copied into the CU's LDS once per workgroup and every lane
-// gathers from there (divergent 16-byte reads: ~10x lower latency than L1 and no tag-lookup serialisation).
-// LDS image: node_a[N] = (x.lo, x.hi, y.lo, y.hi) | node_b[N] = (z.lo, z.hi, skip, packed) | spheres (64 B) |
-// quads (144 B).  The two halves of a node record are separate tables so that lanes reading the same half of
-// different records spread over all 16 four-bank slots (a 32-byte record stride would use only 8).
-template <int LDS> RT_DEV NodeData load_node(const KParams &P, const unsigned char *lds, uint32_t id) {
-    float4 a, b;
-    if constexpr (LDS != 0) {
-        a = reinterpret_cast<const float4 *>(lds)[id];
-        b = reinterpret_cast<const float4 *>(lds + P.lds_off_node_b)[id];
-    } else {
-        const float4 *np = reinterpret_cast<const float4 *>(&P.nodes[id]);
-        a = np[0];
-        b = np[1];
-    }
-    NodeData n;
-    n.lo[0] = a.x; n.hi[0] = a.y; n.lo[1] = a.z; n.hi[1] = a.w; n.lo[2] = b.x; n.hi[2] = b.y;
-    n.skip = __float_as_uint(b.z);
-    n.packed = __float_as_uint(b.w);
-    return n;
-}
-
-// Ordered layout, as the device holds it (global memory and LDS alike): seven tables indexed by record —
-//   X+ | X- | Y+ | Y- | Z+ | Z-   16 bytes each: (child 0, child 1) planes the ray ENTERS through on that axis, then the
-//                                  (child 0, child 1) planes it LEAVES through; "+" for rays with 1/d >= 0 on the axis
-//                                  (enter = lo, leave = hi), "-" the same four values swapped (enter = hi, leave = lo)
-//   R                              8 bytes: the two child references
-// A lane reads ONE of each axis pair, chosen by the sign of its ray's 1/d — the choice is a per-ray byte offset, so
-// the loaded registers already hold (near, near, far, far) pairs ready for the packed fmas: no per-visit selects.
-// Separate tables keep divergent 16-byte reads spread over all LDS banks (as for the threaded records above).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct OPair {
-    f32x2 nx, fx, ny, fy, nz, fz; // entering / leaving planes of (child 0, child 1) per axis
-    uint32_t c0, c1;
-};
-template <int LDS> RT_DEV OPair load_opair(const KParams &P, const unsigned char *lds, uint32_t id, uint32_t offx, uint32_t offy, uint32_t offz) {
-    float4 qx, qy, qz;
-    uint2 r;
-    if constexpr (LDS != 0) { // seven tables
-        qx = *reinterpret_cast<const float4 *>(lds + offx + id * 16u);
-        qy = *reinterpret_cast<const float4 *>(lds + offy + id * 16u);
-        qz = *reinterpret_cast<const float4 *>(lds + offz + id * 16u);
-        r = *reinterpret_cast<const uint2 *>(lds + 6u * P.lds_off_node_b + id * 8u);
-    } else { // global memory: the same seven pieces side by side in one 128-byte line per record (offsets 0 .. 80, 96)
-        const unsigned char *rec = reinterpret_cast<const unsigned char *>(P.oimage) + (size_t)id * 128u;
-        qx = *reinterpret_cast<const float4 *>(rec + offx);
-        qy = *reinterpret_cast<const float4 *>(rec + offy);
-        qz = *reinterpret_cast<const float4 *>(rec + offz);
-        r = *reinterpret_cast<const uint2 *>(rec + 96);
-    }
-    OPair n;
-    n.nx = f32x2{qx.x, qx.y}; n.fx = f32x2{qx.z, qx.w};
-    n.ny = f32x2{qy.x, qy.y}; n.fy = f32x2{qy.z, qy.w};
-    n.nz = f32x2{qz.x, qz.y}; n.fz = f32x2{qz.z, qz.w};
-    n.c0 = r.x;
-    n.c1 = r.y;
-    return n;
-}
-
-// f32 copies of a ray for the conservative box test: origin, 1/d, and a bound E on how far rounding the origin to
-// f32 can move a slab distance on each axis; `degenerate`: some 1/d or E is not finite -> every box is entered.
-struct Ray32 {
-    float ox, oy, oz, ix, iy, iz, ex, ey, ez;
-    bool degenerate;
-};
-RT_DEV Ray32 make_ray32(V3 o, V3 d) {
-    Ray32 r;
-    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
-    // 1/d (the reference's per-visit quotient, src/aabb.rs:66) to f32 accuracy: v_rcp_f32 of the rounded d is within
-    // 2 ulp of it, which the test's slack absorbs (below)
-    r.ix = __builtin_amdgcn_rcpf((float)d.x); r.iy = __builtin_amdgcn_rcpf((float)d.y); r.iz = __builtin_amdgcn_rcpf((float)d.z);
-    // |o - o32| <= 2^-24 |o|, i.e. at most 2^-24 |o| |1/d| in t; E carries a 4x margin
-    r.ex = __builtin_fabsf(r.ox * r.ix) * 0x1p-22f;
-    r.ey = __builtin_fabsf(r.oy * r.iy) * 0x1p-22f;
-    r.ez = __builtin_fabsf(r.oz * r.iz) * 0x1p-22f;
-    const float fsum = (r.ex + r.ey + r.ez) + (__builtin_fabsf(r.ix) + __builtin_fabsf(r.iy) + __builtin_fabsf(r.iz));
-    r.degenerate = !(fsum < __builtin_inff()); // an inf or a NaN anywhere
-    return r;
-}
-// Conservative f32 slab test.  The exact test (f64, interval narrowed axis by axis; equivalent to the reference's
-// un-narrowed one, DESIGN.md "Box test") passes iff max(near) < min(far) over the three slabs and (tmin, tmax).
-// Here: boxes are rounded outward; E bounds the effect of rounding the origin; every computed slab distance
-// (b - o) * (1/d) carries at most 2^-24 (subtraction) + 2^-24 (product) + 2^-22 (1/d: conversion of d, v_rcp_f32)
-// relative error, and tmin / tmax 2^-24 from their conversion: under 2^-21.5 in all.  Each slab's near / far distance
-// is moved outward by its E, and the test declares a miss only if enter still exceeds leave by more than
-// 2^-20 (|enter| + |leave|) — so it passes whenever the exact one does;
-// when it passes although the exact one would not, the visit finds nothing (primitives are intersected in f64).
-// A record without a box carries (-inf, +inf): always passes (inf - inf = NaN compares false).
-RT_DEV bool box_miss_f32(const float lo[3], const float hi[3], const Ray32 &r, float tmin32, float tmax32) {
-    const float t0x = (lo[0] - r.ox) * r.ix, t1x = (hi[0] - r.ox) * r.ix;
-    const float t0y = (lo[1] - r.oy) * r.iy, t1y = (hi[1] - r.oy) * r.iy;
-    const float t0z = (lo[2] - r.oz) * r.iz, t1z = (hi[2] - r.oz) * r.iz;
-    const float enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x) - r.ex, __builtin_fminf(t0y, t1y) - r.ey),
-                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z) - r.ez, tmin32));
-    const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x) + r.ex, __builtin_fmaxf(t0y, t1y) + r.ey),
-                                        __builtin_fminf(__builtin_fmaxf(t0z, t1z) + r.ez, tmax32));
-    const float gap = enter - leave;
-    const float tol = (__builtin_fabsf(enter) + __builtin_fabsf(leave)) * 0x1p-20f;
-    return !r.degenerate && gap > tol; // a NaN compares false: pass
-}
-// The ordered walk tests the two boxes of a record at once, in a form with a third of the instructions: per axis the plane
-// the ray meets first is known from the sign of 1/d (load_opair reads the table laid out for that sign), each slab
-// distance is ONE fused multiply-add
-//     t = b * (1/d) - (o * (1/d) +- E)          (explicit fma: this f32 filter is not part of the f64 arithmetic contract)
-// with the product o * (1/d) and an outward shift E folded into two per-ray constants per axis (`n` for entering planes,
-// `f` for leaving ones), and the verdict is a plain comparison enter > leave.  E is an ABSOLUTE bound on everything that
-// rounding can do to t on that axis, for any plane of the scene: with |b| <= B (the largest coordinate of any box, from the
-// scene compiler) and i = 1/d,
-//     |b i' - b i| <= 2^-22 B |i|           (1/d: conversion of d to f32 + v_rcp_f32)
-//     |p - o i|    <= 1.6 * 2^-22 |o i|      (o -> f32, the same 1/d, the product's rounding)
-//     rounding of p +- E and of the fma: <= 2^-23 (B |i| + |o i|)
-// together under 2^-21 (B |i| + |o i|); E = 2^-20 (B |i| + |o i|) leaves a factor two.  Entering distances are therefore
-// never over-, leaving distances never under-estimated; the interval ends are rounded outward when they are converted
-// (tmin32 down, tmax32 up).  So the test passes whenever the exact one does (tests: rt_debug_box_tests).  In world
-// units E is 2^-20 (B + |o|): random-spheres 2 mm (B = 2000, the ground sphere), Cornell 0.5 mm.
-// The per-ray constants are kept as five register pairs, already negated where the fma subtracts, and each packed fma
-// picks the half it needs for BOTH boxes through op_sel — so nothing has to be duplicated or negated per visit.
-struct RayPair32 {
-    f32x2 ixy;  // (1/d.x, 1/d.y)
-    f32x2 izs;  // (1/d.z, sign bits as float bits: unused half)
-    f32x2 nxy;  // -(o/d + E) on x, y: entering planes
-    f32x2 fxy;  // -(o/d - E) on x, y: leaving planes
-    f32x2 nfz;  // the same two constants on z
-    uint32_t offx, offy, offz; // byte offsets of the tables this ray reads (load_opair): X+ or X-, Y+ or Y-, Z+ or Z-
-    bool degenerate;
-};
-RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes, float extent) {
-    RayPair32 r;
-    const float ix = __builtin_amdgcn_rcpf((float)d.x), iy = __builtin_amdgcn_rcpf((float)d.y), iz = __builtin_amdgcn_rcpf((float)d.z);
-    const float px = (float)o.x * ix, py = (float)o.y * iy, pz = (float)o.z * iz;
-    const float ex = (extent * __builtin_fabsf(ix) + __builtin_fabsf(px)) * 0x1p-20f;
-    const float ey = (extent * __builtin_fabsf(iy) + __builtin_fabsf(py)) * 0x1p-20f;
-    const float ez = (extent * __builtin_fabsf(iz) + __builtin_fabsf(pz)) * 0x1p-20f;
-    r.ixy = f32x2{ix, iy};
-    r.izs = f32x2{iz, 0.0f};
-    r.nxy = f32x2{-(px + ex), -(py + ey)};
-    r.fxy = f32x2{-(px - ex), -(py - ey)};
-    r.nfz = f32x2{-(pz + ez), -(pz - ez)};
-    r.offx = (ix < 0.0f ? 1u : 0u) * table_bytes;
-    r.offy = (iy < 0.0f ? 3u : 2u) * table_bytes;
-    r.offz = (iz < 0.0f ? 5u : 4u) * table_bytes;
-    const float fsum = (ex + ey + ez) + (__builtin_fabsf(ix) + __builtin_fabsf(iy) + __builtin_fabsf(iz));
-    r.degenerate = !(fsum < __builtin_inff()); // an inf or a NaN anywhere: every box is entered
-    return r;
-}
-// planes * (the chosen half of inv, for both boxes) + (the chosen half of off, for both boxes)
-#define RT_PK_FMA_SEL(out, planes, inv, off, SEL)                                                             \
-    asm("v_pk_fma_f32 %0, %1, %2, %3 " SEL : "=v"(out) : "v"(planes), "v"(inv), "v"(off))
-#define RT_SEL_LO_LO "op_sel:[0,0,0] op_sel_hi:[1,0,0]" /* inv.lo, off.lo */
-#define RT_SEL_HI_HI "op_sel:[0,1,1] op_sel_hi:[1,1,1]" /* inv.hi, off.hi */
-#define RT_SEL_LO_HI "op_sel:[0,0,1] op_sel_hi:[1,0,1]" /* inv.lo, off.hi */
-// enter0 / enter1: where the ray enters each box (for choosing which child to walk first: any choice is correct, the
-// nearer one prunes more).  tmin32 / tmax32: the interval, rounded outward.
-RT_DEV void box_pair_f32(const OPair &b, const RayPair32 &r, float tmin32, float tmax32, bool &miss0, bool &miss1, float &enter0,
-                         float &enter1) {
-    f32x2 tnx, tny, tnz, tfx, tfy, tfz;
-    RT_PK_FMA_SEL(tnx, b.nx, r.ixy, r.nxy, RT_SEL_LO_LO);
-    RT_PK_FMA_SEL(tny, b.ny, r.ixy, r.nxy, RT_SEL_HI_HI);
-    RT_PK_FMA_SEL(tnz, b.nz, r.izs, r.nfz, RT_SEL_LO_LO);
-    RT_PK_FMA_SEL(tfx, b.fx, r.ixy, r.fxy, RT_SEL_LO_LO);
-    RT_PK_FMA_SEL(tfy, b.fy, r.ixy, r.fxy, RT_SEL_HI_HI);
-    RT_PK_FMA_SEL(tfz, b.fz, r.izs, r.nfz, RT_SEL_LO_HI);
-    // (v_max3 / v_min3 spelled out: through fmaxf the compiler first "quiets" each operand it cannot prove is no signalling
-    // NaN — one extra instruction per operand, five per visit; the instructions themselves return the non-NaN operand)
-    float en0, en1, le0, le1;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(en0) : "v"(tnx.x), "v"(tny.x), "v"(tnz.x));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(en1) : "v"(tnx.y), "v"(tny.y), "v"(tnz.y));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(le0) : "v"(tfx.x), "v"(tfy.x), "v"(tfz.x));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(le1) : "v"(tfx.y), "v"(tfy.y), "v"(tfz.y));
-    asm("v_max_f32 %0, %1, %2" : "=v"(en0) : "v"(en0), "v"(tmin32));
-    asm("v_max_f32 %0, %1, %2" : "=v"(en1) : "v"(en1), "v"(tmin32));
-    asm("v_min_f32 %0, %1, %2" : "=v"(le0) : "v"(le0), "v"(tmax32));
-    asm("v_min_f32 %0, %1, %2" : "=v"(le1) : "v"(le1), "v"(tmax32));
-    miss0 = !r.degenerate && en0 > le0; // a NaN compares false: pass
-    miss1 = !r.degenerate && en1 > le1;
-    enter0 = en0;
-    enter1 = en1;
-}
-// one box given as (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi) in both slots of a pair, as the "+" / "-" tables would hold it
-RT_DEV OPair opair_of_box(const float b[6], const RayPair32 &r) {
-    OPair p;
-    const bool sx = r.ixy.x < 0.0f, sy = r.ixy.y < 0.0f, sz = r.izs.x < 0.0f;
-    p.nx = f32x2{sx ? b[1] : b[0], sx ? b[1] : b[0]}; p.fx = f32x2{sx ? b[0] : b[1], sx ? b[0] : b[1]};
-    p.ny = f32x2{sy ? b[3] : b[2], sy ? b[3] : b[2]}; p.fy = f32x2{sy ? b[2] : b[3], sy ? b[2] : b[3]};
-    p.nz = f32x2{sz ? b[5] : b[4], sz ? b[5] : b[4]}; p.fz = f32x2{sz ? b[4] : b[5], sz ? b[4] : b[5]};
-    p.c0 = p.c1 = 0;
-    return p;
-}
-// The exact f64 test the kernel used before (and the oracle's tight mode): kept as the yardstick for the test hook
-RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, double tmin, double tmax) {
-    const double od[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-    for (int ax = 0; ax < 3; ++ax) {
-        const double inv = 1.0 / dd[ax];
-        double t0 = (lo[ax] - od[ax]) * inv, t1 = (hi[ax] - od[ax]) * inv;
-        if (inv < 0.0) { const double tt = t0; t0 = t1; t1 = tt; }
-        tmin = __builtin_fmax(t0, tmin);
-        tmax = __builtin_fmin(t1, tmax);
-        if (tmax <= tmin) return true;
-    }
-    return false;
-}
 
 // LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = + sphere table; 3 = + quad table
 // ORDERED: walk the compiler's own trees nearest child first (scenes without a ConstantMedium), else the threaded
@@ -518,7 +170,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     const uint32_t att_stride = P.n_threads * 3u; // (32-bit element indices: launch_render checks the stack has < 2^32 doubles)
 
     // wave-uniform: the job range this wave currently owns
-    uint32_t job_next = 0, job_end = 0;
+    uint32_t job_next = 0, job_end = 0, jobs_seen_left = P.n_jobs;
     bool jobs_left = true;
 
     const uint32_t n_nodes = P.n_nodes;
@@ -975,6 +627,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, texs_tab, perlin_tab, m->texture, u, v, p, cn);
                     else tex = ld3(m->albedo); // every texture is a SolidColor (src/texture.rs:32-36): the colour was copied here
                 }
+                PROF_MARK(8);
                 V3 attenuation = tex;
                 bool unit_attenuation = false;
                 V3 new_dir = normal;
@@ -1022,6 +675,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         d = new_dir;
                     }
                 }
+                PROF_MARK(9);
                 if (path_done) {
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
                         // a light: the emitted colour is parked like one more attenuation and the path ends on Color::ONE
@@ -1068,22 +722,36 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 dst[0] = result.x; dst[1] = result.y; dst[2] = result.z;
                 stage = ST_NEWJOB + TERM_STORED;
             }
+            PROF_MARK(10);
             // ---- hand out jobs to the lanes that need one (wave-level: ballot + prefix count) ----
             const uint64_t want = __ballot(here);
             const uint32_t n_want = (uint32_t)__popcll(want);
             if (n_want) {
-                if (jobs_left && job_next == job_end) { // the wave's range is used up: reserve the next one
+                // what is left of the wave's current range goes out first; if that does not serve every asking lane, the next
+                // range is reserved in the same round (a lane left without a job would idle until the next path-end round)
+                const uint32_t old_next = job_next, old_avail = job_end - job_next;
+                uint32_t new_base = 0, new_avail = 0;
+                if (jobs_left && old_avail < n_want) {
+                    // guided hand-out: the grabs shrink as the launch runs out (never more than taper x what was left when this
+                    // wave last looked — its previous reservation told it —, in whole sample-rows of a tile), so that the slowest
+                    // wave's last grab, the tail of the launch, is short although the early grabs are large.  Any sizes tile the job
+                    // range, so a stale estimate is harmless.  (No extra look at the counter: 4096 waves reading and adding to one
+                    // word already approach what one L2 line serves — MI355X_MICROARCH.md "dequeue": ~88 per microsecond.)
+                    uint32_t grab = (uint32_t)((float)jobs_seen_left * P.grab_taper) & ~63u;
+                    grab = grab < P.jobs_per_grab ? grab : P.jobs_per_grab;
+                    grab = grab < MIN_JOBS_PER_GRAB ? MIN_JOBS_PER_GRAB : grab;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.job_counter, P.jobs_per_grab);
+                    if (lane == 0) base = atomicAdd(P.job_counter, grab);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    jobs_seen_left = base + grab < P.n_jobs ? P.n_jobs - (base + grab) : 0u;
                     if (base >= P.n_jobs) { jobs_left = false; }
-                    else { job_next = base; job_end = base + P.jobs_per_grab < P.n_jobs ? base + P.jobs_per_grab : P.n_jobs; }
+                    else { new_base = base; new_avail = (base + grab < P.n_jobs ? base + grab : P.n_jobs) - base; }
                 }
-                const uint32_t avail = job_end - job_next;
+                const uint32_t avail = old_avail + new_avail;
                 const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                 if (here) {
                     if (rank < avail) {
-                        job = job_next + rank;
+                        job = rank < old_avail ? old_next + rank : new_base + (rank - old_avail);
                         // job -> (local tile, sample, pixel): ((lt * S + s_rel) * 64 + p)
                         const uint32_t p64 = job & 63u;
                         const uint32_t row = job >> 6;
@@ -1132,8 +800,11 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         stage = ST_DONE;
                     }
                 }
-                job_next += n_want < avail ? n_want : avail;
+                const uint32_t taken = n_want < avail ? n_want : avail;
+                if (new_avail) { job_next = new_base + (taken - old_avail); job_end = new_base + new_avail; }
+                else job_next = old_next + taken;
             }
+            PROF_MARK(11);
         }
         if (start_query) { // the closest-hit query of a scattered or camera ray: world.hit(r, (0.001, inf)) (src/renderer.rs:144)
             if (COUNT) cn.rays++;
@@ -1340,3 +1011,4 @@ void launch_debug_eval(int32_t op, int64_t n, const double *a, const double *b, 
 }
 
 } // namespace rtk
+

@@ -48,6 +48,7 @@ struct KParams {
     uint32_t n_samples;             // samples per pixel in this launch
     uint32_t n_jobs;                // n_local_tiles * n_samples * 64
     uint32_t jobs_per_grab;
+    float grab_taper;               // a grab takes at most this fraction of the jobs still to hand out (guided self-scheduling)
     double inv_n_samples, inv_tiles_x; // 1 / n_samples, 1 / tiles_x (job decode)
     int32_t max_depth, accumulate;
     int32_t shard_index, shard_count, out_layout;
@@ -84,11 +85,13 @@ enum Feature : uint32_t {
 };
 constexpr uint32_t F_ALL = 31u;
 
-constexpr uint32_t PROF_SLOTS = 8;       // COUNT kernels: profile slots per wave (6 stages + 2 parts of the shade stage)
+constexpr uint32_t PROF_SLOTS = 12;      // COUNT kernels: profile slots per wave (6 stages + 6 parts of the shade / path-end rounds)
+constexpr uint32_t COUNTER_WORDS = 10 + PROF_SLOTS * 3; // rt_counters as 10 u64, then per profile slot: rounds, active lanes, cycles
 // Jobs a wave reserves at a time: a multiple of 64 (one sample-row of an 8x8 tile, so the lanes a wave starts together
 // trace neighbouring pixels).  Large grabs mean few atomics; small ones a short tail (the last grab of the slowest wave
 // is all that is left running at the end): launch_render picks the size so that every wave gets at least ~32 grabs.
-constexpr uint32_t MAX_JOBS_PER_GRAB = 1024, MIN_JOBS_PER_GRAB = 64;
+// (one device counter serves every wave: reservations have to stay well under ~88 per microsecond machine-wide)
+constexpr uint32_t MAX_JOBS_PER_GRAB = 1024, MIN_JOBS_PER_GRAB = 128, MIN_JOBS_PER_WAVE = 256;
 
 constexpr int GLOBAL_THREADS = 256;             // scene gathered from global memory: 256-thread blocks
 #ifndef RT_LDS_THREADS

@@ -25,7 +25,7 @@ total = sum(v["cycles"] for v in prof.values())
 n = cnt["samples"]
 print({k: round(v / n, 3) for k, v in cnt.items()})
 for k, v in prof.items():
-    if k.startswith("shade."):
+    if "." in k:
         print(f"  {k:15s} cycles {100 * v['cycles'] / total:5.1f} %")
         continue
     print(f"{k:7s} rounds/sample {v['rounds'] * 64 / n:9.2f}  mean active lanes {v['mean_active_lanes']:5.1f}  cycles {100 * v['cycles'] / total:5.1f} %"
