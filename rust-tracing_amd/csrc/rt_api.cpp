@@ -56,17 +56,29 @@ uint64_t host_mix64(uint64_t z) {
 
 uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return s->lds_prefix_bytes[lds]; }
 // the LDS image, then (ordered walk) the per-lane stacks: 2-byte entries beside an LDS-resident scene, else 4-byte
+int block_threads(const rt_scene *s, int lds) { return kernel_threads_for(kernel_features_for(s->features, lds, s->ordered), lds); }
 size_t stack_bytes(const rt_scene *s, int lds) {
     if (!s->ordered) return 0;
-    return (size_t)s->o_stack * (lds ? (size_t)LDS_THREADS * 2u : (size_t)GLOBAL_THREADS * 4u);
+    return (size_t)s->o_stack * (size_t)block_threads(s, lds) * (lds ? 2u : 4u);
 }
-size_t prof_bytes(int lds) { return (size_t)((lds ? LDS_THREADS : GLOBAL_THREADS) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
-size_t seq_offset(const rt_scene *s, int lds) { return (lds_image_bytes_for(s, lds) + stack_bytes(s, lds) + 15u) & ~(size_t)15u; }
-size_t aux_offset(const rt_scene *s, int lds) { return (seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u) + 15u) & ~(size_t)15u; }
-bool aux_in_lds(const rt_scene *s, int lds) { return lds == 0 && s->aux_bytes != 0; }
-size_t prof_offset(const rt_scene *s, int lds) { return aux_offset(s, lds) + (aux_in_lds(s, lds) ? s->aux_bytes : 0u); }
+size_t prof_bytes(const rt_scene *s, int lds) { return (size_t)(block_threads(s, lds) / 64) * PROF_SLOTS * 3u * sizeof(unsigned long long); }
+// behind the image and the stacks: the world's sequence | the small tables (AUX kernels) | parked world rays | profile rows —
+// the optional parts are taken in this order for as long as the CU's LDS has room (the instrumented kernel's rows included,
+// so that it has the layout of the one it stands in for)
+size_t align16(size_t x) { return (x + 15u) & ~(size_t)15u; }
+size_t seq_offset(const rt_scene *s, int lds) { return align16(lds_image_bytes_for(s, lds) + stack_bytes(s, lds)); }
+size_t aux_offset(const rt_scene *s, int lds) { return align16(seq_offset(s, lds) + (s->ordered ? (size_t)s->n_oseq * sizeof(OSeq) : 0u)); }
+bool aux_in_lds(const rt_scene *s, int lds) {
+    return s->ordered && s->aux_bytes != 0 && aux_offset(s, lds) + s->aux_bytes + prof_bytes(s, lds) <= LDS_BUDGET_BYTES;
+}
+size_t world_offset(const rt_scene *s, int lds) { return align16(aux_offset(s, lds) + (aux_in_lds(s, lds) ? s->aux_bytes : 0u)); }
+size_t world_bytes(const rt_scene *s, int lds) { return (size_t)6 * sizeof(double) * (size_t)block_threads(s, lds); }
+bool world_in_lds(const rt_scene *s, int lds) {
+    return s->has_instances && world_offset(s, lds) + world_bytes(s, lds) + prof_bytes(s, lds) <= LDS_BUDGET_BYTES;
+}
+size_t prof_offset(const rt_scene *s, int lds) { return world_offset(s, lds) + (world_in_lds(s, lds) ? world_bytes(s, lds) : 0u); }
 size_t dynamic_lds_bytes(const rt_scene *s, int lds, bool counted) {
-    return prof_offset(s, lds) + (counted ? prof_bytes(lds) : 0);
+    return prof_offset(s, lds) + (counted ? prof_bytes(s, lds) : 0);
 }
 
 template <class T> int upload(DeviceArray<T> &dst, const std::vector<T> &src) {
@@ -161,7 +173,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
 
     const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
-    const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+    const int threads = block_threads(scene, lds);
     const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
     const size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
     // persistent grid: every resident wave pulls jobs until none are left
@@ -251,6 +263,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.world_slots = ws.world_slots;
+    K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
@@ -332,14 +345,14 @@ int64_t rt_out_size(int32_t width, int32_t height, int32_t out_layout, int32_t s
     return -1;
 }
 
-// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py), own trees vs reference
-// order, Msamples/s: two_spheres 3978 / 4813, earth 15970 / 19317, two_perlin_spheres 2349 / 2651, simple_light 3060 /
-// 3322 (1-4 primitives: a tree and a stack are overhead); quads 15790 / 14393, cornell_box 2206 / 1967, random_balls 3557 /
-// 2038, final_scene 821 / 624; cornell_smoke 496 / 736 (18 quads, and two media whose rotated-box boundaries are walked as
-// trees of their own, twice per visit).
+// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py, round 2: small tables and parked
+// world rays in the LDS, 768-thread every-feature kernels), own trees vs reference order, Msamples/s: two_spheres 6713 / 6381,
+// earth 20107 / 20514 (one primitive: a tree and a stack are pure overhead), two_perlin_spheres 4079 / 3234, simple_light
+// 5392 / 4744, cornell_smoke 947 / 977 (18 quads, and two media whose rotated-box boundaries are walked as trees of their own,
+// twice per visit); round 1: quads 15790 / 14393, cornell_box 2206 / 1967, random_balls 3557 / 2038, final_scene 821 / 624.
 static bool ordered_walk_pays(const CompiledScene &cs) {
     const size_t prims = cs.spheres.size() + cs.quads.size();
-    if (prims <= 4) return false;
+    if (prims <= 1) return false;
     bool general_boundary = false;
     for (const Node &n : cs.nodes)
         if ((n.kind & NODE_KIND_MASK) == NK_MEDIUM_ENTER) general_boundary = true;
@@ -452,11 +465,11 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         s->lds_off_node_b = (uint32_t)off_b;
         const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
         const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
-        const size_t stack = stack_bytes(s, 1);
+        const size_t stack3 = stack_bytes(s, 3), stack1 = stack_bytes(s, 1); // (the two levels' kernels differ in workgroup size)
         // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
         // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
         const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
-        s->lds_level = total + stack <= budget ? 3 : (off_sph + stack <= budget ? 1 : 0);
+        s->lds_level = total + stack3 <= budget ? 3 : (off_sph + stack1 <= budget ? 1 : 0);
         if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits
         if (s->lds_level) {
             const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
@@ -494,22 +507,24 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         mats[i] = d;
     }
 
-    // AUX image (path_kernel's AUX): the small tables, for ordered scenes whose big tables stay in global memory
+    // AUX image (path_kernel's AUX): the small tables an ordered scene's kernel reads per hit — materials, frames, media, and
+    // (only when some texture is not a SolidColor: otherwise the colours sit in the material records) textures and Perlin
+    // tables; copied into the LDS wherever it fits (aux_in_lds)
     {
-        auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
+        const bool with_textures = (s->features & F_TEXTURES) != 0;
         const size_t o_mats = 0, o_texs = align16(o_mats + mats.size() * sizeof(DMaterial)),
-                     o_insts = align16(o_texs + cs.textures.size() * sizeof(rt_texture)),
+                     o_insts = align16(o_texs + (with_textures ? cs.textures.size() * sizeof(rt_texture) : 0u)),
                      o_media = align16(o_insts + cs.instances.size() * sizeof(Instance)),
                      o_perlins = align16(o_media + cs.media.size() * sizeof(Medium)),
-                     total = align16(o_perlins + cs.perlins.size() * sizeof(rt_perlin));
-        if (s->ordered && s->lds_level == 0 && total > 0 && total <= 24 * 1024) {
+                     total = align16(o_perlins + (with_textures ? cs.perlins.size() * sizeof(rt_perlin) : 0u));
+        if (s->ordered && total > 0 && total <= 48 * 1024) {
             std::vector<uint4> img(total / 16);
             unsigned char *base = reinterpret_cast<unsigned char *>(img.data());
             if (!mats.empty()) memcpy(base + o_mats, mats.data(), mats.size() * sizeof(DMaterial));
-            if (!cs.textures.empty()) memcpy(base + o_texs, cs.textures.data(), cs.textures.size() * sizeof(rt_texture));
+            if (with_textures && !cs.textures.empty()) memcpy(base + o_texs, cs.textures.data(), cs.textures.size() * sizeof(rt_texture));
             if (!cs.instances.empty()) memcpy(base + o_insts, cs.instances.data(), cs.instances.size() * sizeof(Instance));
             if (!cs.media.empty()) memcpy(base + o_media, cs.media.data(), cs.media.size() * sizeof(Medium));
-            if (!cs.perlins.empty()) memcpy(base + o_perlins, cs.perlins.data(), cs.perlins.size() * sizeof(rt_perlin));
+            if (with_textures && !cs.perlins.empty()) memcpy(base + o_perlins, cs.perlins.data(), cs.perlins.size() * sizeof(rt_perlin));
             int urc = upload(s->aux_image, img);
             if (urc != RT_OK) { free_scene(s); return urc; }
             s->aux_bytes = (uint32_t)total;
@@ -521,7 +536,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         for (int counted = 0; counted < 2; ++counted) {
             if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
             const void *fn = path_kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered, aux_in_lds(s, lds));
-            const int threads = lds ? LDS_THREADS : GLOBAL_THREADS;
+            const int threads = block_threads(s, lds);
             const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
             int b = 0;

@@ -82,9 +82,32 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     const Instance *const inst_tab = AUX ? reinterpret_cast<const Instance *>(lds_raw + P.lds_aux_off + P.aux_off_insts) : P.insts;
     const Medium *const media_tab = AUX ? reinterpret_cast<const Medium *>(lds_raw + P.lds_aux_off + P.aux_off_media) : P.media;
     const rt_perlin *const perlin_tab = AUX ? reinterpret_cast<const rt_perlin *>(lds_raw + P.lds_aux_off + P.aux_off_perlins) : P.perlins;
-    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree) is parked in global
-    // memory (touched 0.3-2.6 times per sample; the LDS is worth more as scene storage)
-    double *const world_slot = P.world_slots + gtid;
+    // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree) is parked in the LDS where
+    // the scene leaves room (Cornell: a frame exit waited for six loads from memory, a fifth of the frame's cycles went there),
+    // else in global memory (touched 0.3-2.6 times per sample)
+    const bool world_in_lds = P.lds_world_off != 0xffffffffu;
+    double *const world_lds = reinterpret_cast<double *>(lds_raw + (world_in_lds ? P.lds_world_off : 0u)) + threadIdx.x;
+    double *const world_glb = P.world_slots + gtid;
+    auto park_world_ray = [&](V3 po, V3 pd) {
+        if (world_in_lds) {
+            world_lds[0] = po.x; world_lds[THREADS] = po.y; world_lds[2 * THREADS] = po.z;
+            world_lds[3 * THREADS] = pd.x; world_lds[4 * THREADS] = pd.y; world_lds[5 * THREADS] = pd.z;
+        } else {
+            const size_t ws = P.n_threads;
+            world_glb[0] = po.x; world_glb[ws] = po.y; world_glb[2 * ws] = po.z;
+            world_glb[3 * ws] = pd.x; world_glb[4 * ws] = pd.y; world_glb[5 * ws] = pd.z;
+        }
+    };
+    auto restore_world_ray = [&](V3 &ro, V3 &rd) {
+        if (world_in_lds) {
+            ro = v3(world_lds[0], world_lds[THREADS], world_lds[2 * THREADS]);
+            rd = v3(world_lds[3 * THREADS], world_lds[4 * THREADS], world_lds[5 * THREADS]);
+        } else {
+            const size_t ws = P.n_threads;
+            ro = v3(world_glb[0], world_glb[ws], world_glb[2 * ws]);
+            rd = v3(world_glb[3 * ws], world_glb[4 * ws], world_glb[5 * ws]);
+        }
+    };
 
     Counts cn{};
     Rng rng;
@@ -168,6 +191,15 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
 
     double *att = P.att_stack + (size_t)gtid * 3u;
     const uint32_t att_stride = P.n_threads * 3u; // (32-bit element indices: launch_render checks the stack has < 2^32 doubles)
+    // A path that has ended waits for the path-end round; its ray registers are dead by then.  The loads of the last two
+    // attenuations it parked are issued at once into them (o: the last one parked, d: the one before), so that the round that
+    // multiplies them back does not start with a trip to memory (measured: a tenth of the frame's cycles on C2 and C4).
+    const bool background_lit = P.cam.background.x != 0.0 || P.cam.background.y != 0.0 || P.cam.background.z != 0.0;
+    auto prefetch_parked = [&]() {
+        if (!background_lit) return; // (a path that ends on a black background is zero whatever it parked)
+        if (n_att > 0) { const double *slot = att + (n_att - 1u) * att_stride; o = v3(slot[0], slot[1], slot[2]); }
+        if (n_att > 1) { const double *slot = att + (n_att - 2u) * att_stride; d = v3(slot[0], slot[1], slot[2]); }
+    };
 
     // wave-uniform: the job range this wave currently owns
     uint32_t job_next = 0, job_end = 0, jobs_seen_left = P.n_jobs;
@@ -327,7 +359,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         const uint32_t c_quad = HAS_QUADS ? (uint32_t)__popcll(__ballot(stage == ST_QUAD)) : 0u;
         const uint32_t c_oth = HAS_OTHER ? (uint32_t)__popcll(__ballot(stage == ST_OTHER)) : 0u;
         // a finished query that hit nothing needs no shading: the path ends on the background
-        if (stage == ST_SHADE && best_prim == PRIM_NONE) stage = ST_NEWJOB + TERM_BACKGROUND;
+        if (stage == ST_SHADE && best_prim == PRIM_NONE) {
+            stage = ST_NEWJOB + TERM_BACKGROUND;
+            prefetch_parked();
+        }
         // th_new == 0: no separate path-end rounds — every shade round ends with the path-end block (for its own lanes that
         // just finished and any that were waiting), and the two queues count as one (measured better on final_scene)
         const bool merged = HAS_TEXTURES || P.th_new == 0; // (the general kernels are always merged: less code, fewer spills)
@@ -493,18 +528,13 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 } else
                 if (stage == ST_OTHER) { // enter the frame of instance `node`, or leave the current one
                     const bool leaving = node == NODE_FRAME_EXIT;
-                    const size_t ws = P.n_threads;
                     if (leaving) {
                         cur_inst = inst_tab[cur_inst].parent;
-                        o = v3(world_slot[0], world_slot[ws], world_slot[2 * ws]);
-                        d = v3(world_slot[3 * ws], world_slot[4 * ws], world_slot[5 * ws]);
+                        restore_world_ray(o, d);
                         ray_to_frame(inst_tab, cur_inst, o, d);
                     } else {
                         if (COUNT) cn.instance_enters++;
-                        if (cur_inst < 0) { // leaving the world frame: park the world ray
-                            world_slot[0] = o.x; world_slot[ws] = o.y; world_slot[2 * ws] = o.z;
-                            world_slot[3 * ws] = d.x; world_slot[4 * ws] = d.y; world_slot[5 * ws] = d.z;
-                        }
+                        if (cur_inst < 0) park_world_ray(o, d); // leaving the world frame
                         apply_instance(inst_tab[node], o, d);
                         cur_inst = (int32_t)node;
                         stack[sp * THREADS] = (StackT)S_EXIT;
@@ -522,19 +552,13 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 const uint32_t na = nd.packed >> N32_A_SHIFT;
                 if (HAS_FRAMES && kind == NK_INST_ENTER) {
                     if (COUNT) cn.instance_enters++;
-                    if (cur_inst < 0) { // leaving the world frame: park the world ray
-                        const size_t ws = P.n_threads;
-                        world_slot[0] = o.x; world_slot[ws] = o.y; world_slot[2 * ws] = o.z;
-                        world_slot[3 * ws] = d.x; world_slot[4 * ws] = d.y; world_slot[5 * ws] = d.z;
-                    }
+                    if (cur_inst < 0) park_world_ray(o, d); // leaving the world frame
                     apply_instance(inst_tab[na], o, d);
                     cur_inst = (int32_t)na;
                     node = node + 1;
                 } else if (HAS_FRAMES && kind == NK_INST_EXIT) {
                     cur_inst = inst_tab[na].parent;
-                    const size_t ws = P.n_threads;
-                    o = v3(world_slot[0], world_slot[ws], world_slot[2 * ws]);
-                    d = v3(world_slot[3 * ws], world_slot[4 * ws], world_slot[5 * ws]);
+                    restore_world_ray(o, d);
                     ray_to_frame(inst_tab, cur_inst, o, d);
                     node = node + 1;
                 } else if (HAS_MEDIA && kind == NK_MEDIUM_ENTER) { // boundary.hit(r, UNIVERSE) (src/constant_medium.rs:35)
@@ -680,8 +704,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
                         // a light: the emitted colour is parked like one more attenuation and the path ends on Color::ONE
                         // (emitted * 1.0 is emitted, bit for bit), so the chain of products is written once, in ST_NEWJOB
-                        double *slot = att + n_att * att_stride;
-                        slot[0] = result.x; slot[1] = result.y; slot[2] = result.z;
+                        // (nothing is stored: the two registers the path-end round reads first are filled here)
+                        if (n_att > 0) { const double *below = att + (n_att - 1u) * att_stride; d = v3(below[0], below[1], below[2]); }
+                        o = result;
                         n_att++;
                         stage = ST_NEWJOB + TERM_ONE;
                     } else {
@@ -700,9 +725,13 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 V3 result = v3(0.0, 0.0, 0.0);
                 if (term != TERM_ZERO) {
                     result = term == TERM_BACKGROUND ? from(P.cam.background) : v3(1.0, 1.0, 1.0);
-                    // up to CHAIN parked attenuations per trip, their loads issued together (one memory latency, not CHAIN); the
-                    // products still run one after the other, last parked first.  A zero terminal stays zero (attenuations are finite).
+                    // the last two parked attenuations are in o and d already (prefetch_parked); below them, up to CHAIN per trip,
+                    // their loads issued together (one memory latency, not CHAIN); the products still run one after the other, last
+                    // parked first.  A zero terminal stays zero (attenuations are finite).
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
+                        if (n_att > 0) result = o * result;
+                        if (n_att > 1) result = d * result;
+                        n_att = n_att > 2u ? n_att - 2u : 0u;
                         while (n_att > 0) {
                             V3 parked[CHAIN];
                     #pragma unroll
@@ -961,27 +990,29 @@ uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
     (void)ordered;
     return F_ALL;
 }
+int kernel_threads_for(uint32_t kernel_features, int lds) {
+    if (lds == 0) return GLOBAL_THREADS;
+    return kernel_features == F_ALL ? LDS_THREADS_GENERAL : LDS_THREADS;
+}
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
-#define RT_PICK(L, T, F, O) (counted ? (const void *)path_kernel<true, L, T, F, O> : (const void *)path_kernel<false, L, T, F, O>)
-    if (ordered && lds == 0 && aux)
-        return counted ? (const void *)path_kernel<true, 0, GLOBAL_THREADS, F_ALL, true, true> : (const void *)path_kernel<false, 0, GLOBAL_THREADS, F_ALL, true, true>;
-    if (ordered) {
+#define RT_PICK(L, T, F, O, A) (counted ? (const void *)path_kernel<true, L, T, F, O, A> : (const void *)path_kernel<false, L, T, F, O, A>)
+    if (ordered) { // (AUX: the small tables in the LDS as well, wherever they fit — rt_api.cpp decides)
         if (lds == 3) {
-            if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true);
-            if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true);
-            return RT_PICK(3, LDS_THREADS, F_ALL, true);
+            if (feat == FEAT_SPHERES_SOLID) return aux ? RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true, true) : RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true, false);
+            if (feat == FEAT_QUADS_FRAMES) return aux ? RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true, true) : RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true, false);
+            return aux ? RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, true, true) : RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, true, false);
         }
-        if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL, true);
-        return RT_PICK(0, GLOBAL_THREADS, F_ALL, true);
+        if (lds == 1) return aux ? RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, true, true) : RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, true, false);
+        return aux ? RT_PICK(0, GLOBAL_THREADS, F_ALL, true, true) : RT_PICK(0, GLOBAL_THREADS, F_ALL, true, false);
     }
     if (lds == 3) {
-        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false);
-        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, false);
-        return RT_PICK(3, LDS_THREADS, F_ALL, false);
+        if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false, false);
+        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, false, false);
+        return RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, false, false);
     }
-    if (lds == 2) return RT_PICK(2, LDS_THREADS, F_ALL, false);
-    if (lds == 1) return RT_PICK(1, LDS_THREADS, F_ALL, false);
-    return RT_PICK(0, GLOBAL_THREADS, F_ALL, false);
+    if (lds == 2) return RT_PICK(2, LDS_THREADS_GENERAL, F_ALL, false, false);
+    if (lds == 1) return RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, false, false);
+    return RT_PICK(0, GLOBAL_THREADS, F_ALL, false, false);
 #undef RT_PICK
 }
 

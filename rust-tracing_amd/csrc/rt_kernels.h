@@ -61,6 +61,7 @@ struct KParams {
     uint32_t lds_image_bytes;
     uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
     double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
+    uint32_t lds_world_off;         // ... or, where the LDS has room, [6][block threads] doubles there (0xffffffff: global memory)
     // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
     const uint4 *oimage;            // the seven tables of load_opair, in global memory (LDS kernels copy them in)
     const OSeq *oseq;               // the world frame's sequence of trees and media (rt_layout.h)
@@ -98,6 +99,10 @@ constexpr int GLOBAL_THREADS = 256;             // scene gathered from global me
 #define RT_LDS_THREADS 1024 // 16 waves = 4 per SIMD (tools/tune.py: 512 -> 1381, 768 -> 1774, 1024 -> 1921 Msamples/s on C2 at 48 spp)
 #endif
 constexpr int LDS_THREADS = RT_LDS_THREADS;     // scene in LDS: one 16-wave workgroup per CU shares the copy
+#ifndef RT_LDS_THREADS_GENERAL
+#define RT_LDS_THREADS_GENERAL 768 // the every-feature kernels: 12 waves = 3 per SIMD, 170 registers each (at 128 they spill 80-140 of them)
+#endif
+constexpr int LDS_THREADS_GENERAL = RT_LDS_THREADS_GENERAL;
 constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 
 // The kernel instantiations that exist: the general one (every feature) at each LDS level, plus specialised
@@ -105,6 +110,7 @@ constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
 constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
+int kernel_threads_for(uint32_t kernel_features, int lds); // workgroup size of that instantiation
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux);
 
 // launches of the small kernels (all asynchronous on `stream`; errors through hipGetLastError)

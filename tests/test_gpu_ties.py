@@ -136,9 +136,9 @@ def test_random_object_graphs(rt, oracle, gpu):
 
 def test_default_choice_of_the_walk(rt, gpu):
     """By default a scene gets the library's own trees unless the reference-order walk measured faster for its kind
-    (DESIGN.md "Ordered layout"): 1-4 primitives; small scenes with box-bounded media."""
-    want = {"c1_random_balls_400x225_10spp_d10": 1, "two_spheres_80x45_8spp": 0, "earth_80x45_8spp": 0, "two_perlin_spheres_80x45_8spp": 0,
-            "quads_64x64_8spp": 1, "simple_light_80x45_16spp": 0, "c3_cornell_box_64x64_16spp_d50": 1, "cornell_smoke_64x64_16spp": 0,
+    (DESIGN.md "Ordered layout"): a single primitive; small scenes with box-bounded media."""
+    want = {"c1_random_balls_400x225_10spp_d10": 1, "two_spheres_80x45_8spp": 1, "earth_80x45_8spp": 0, "two_perlin_spheres_80x45_8spp": 1,
+            "quads_64x64_8spp": 1, "simple_light_80x45_16spp": 1, "c3_cornell_box_64x64_16spp_d50": 1, "cornell_smoke_64x64_16spp": 0,
             "c4_final_scene_64x64_8spp_d40": 1}
     for name, ordered in want.items():
         assert rt.DeviceScene(scene_cases.build(rt, name)).stats()["ordered"] == ordered, name
