@@ -35,6 +35,11 @@ WORKLOADS = {
     "c5": dict(name="final_scene 1600x1600, 10000 spp, depth 50", scene=8, width=1600, aspect=1.0, spp=10000, depth=50,
                earth_image="synthetic:6400x3200"),
 }
+# final_scene's image texture: the reference's own asset (assets/README.md), decoded by the host library's JPEG decoder; the
+# procedural stand-in of the same size only if the file is missing
+EARTH = str(ROOT / "assets" / "earth-large.jpg") if (ROOT / "assets" / "earth-large.jpg").exists() else "synthetic:6400x3200"
+for _w in ("c4", "c5"):
+    WORKLOADS[_w]["earth_image"] = EARTH
 SCENE_SEED = 1
 RENDER_SEED = 1
 

@@ -23,7 +23,7 @@ int fail(int status, const std::string &msg) {
 Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_OVERLAP", overlap);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
     if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
@@ -99,16 +99,27 @@ bool texture_needs_uv(const std::vector<rt_texture> &texs, int32_t t, int depth 
     return false;
 }
 
+} // namespace
+
+namespace rtapi {
+void free_workspace(Workspace &w) {
+    for (int h = 0; h < 2; ++h) {
+        (void)hipFree(w.half[h].att_stack); (void)hipFree(w.half[h].samples); (void)hipFree(w.half[h].world_slots); (void)hipFree(w.half[h].job_counter);
+        if (w.aux[h]) (void)hipStreamDestroy(w.aux[h]);
+        if (w.ev_sum[h]) (void)hipEventDestroy(w.ev_sum[h]);
+    }
+    if (w.ev_start) (void)hipEventDestroy(w.ev_start);
+    (void)hipFree(w.counters);
+    w = Workspace();
+}
+} // namespace rtapi
+
+namespace {
+
 void free_scene(rt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    for (auto &kv : s->workspaces) {
-        (void)hipFree(kv.second.att_stack);
-        (void)hipFree(kv.second.samples);
-        (void)hipFree(kv.second.world_slots);
-        (void)hipFree(kv.second.job_counter);
-        (void)hipFree(kv.second.counters);
-    }
+    for (auto &kv : s->workspaces) free_workspace(kv.second);
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
     (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr); (void)hipFree(s->aux_image.ptr);
@@ -164,13 +175,20 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
     const Tuning tn = effective_tuning(scene);
 
-    // samples per launch: bounded by the sample buffer and by the 32-bit job index
+    // samples per launch: bounded by the sample buffer and by the 32-bit job index.  A frame that needs more than one launch is
+    // pipelined over two scratch sets (half the budget each) unless that is switched off or the kernel is the instrumented one.
     const int64_t bytes_per_sample_row = n_local * 64 * 3 * (int64_t)sizeof(double);
-    int64_t chunk = (int64_t)(tn.sample_buffer_bytes / (size_t)bytes_per_sample_row);
     const int64_t max_by_index = ((int64_t)1 << 31) / (n_local * 64);
-    if (chunk > max_by_index) chunk = max_by_index;
-    if (chunk > n_samples_total) chunk = n_samples_total;
+    auto chunk_for = [&](size_t budget) {
+        int64_t c = (int64_t)(budget / (size_t)bytes_per_sample_row);
+        if (c > max_by_index) c = max_by_index;
+        if (c > n_samples_total) c = n_samples_total;
+        return c;
+    };
+    int64_t chunk = chunk_for(tn.sample_buffer_bytes);
     if (chunk < 1) return fail(RT_ERR_UNSUPPORTED, "rt_render: one sample per pixel does not fit the sample buffer");
+    bool pipelined = !counted && tn.overlap != 0 && chunk < n_samples_total && chunk_for(tn.sample_buffer_bytes / 2) >= 1;
+    if (pipelined) chunk = chunk_for(tn.sample_buffer_bytes / 2);
 
     const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
     const int threads = block_threads(scene, lds);
@@ -192,8 +210,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             // a new stream and the table is full: release the others' buffers once their work has drained
             for (auto &kv : scene->workspaces) {
                 (void)hipStreamSynchronize(kv.first); // (a stream that no longer exists: nothing of it is in flight)
-                (void)hipFree(kv.second.att_stack); (void)hipFree(kv.second.samples); (void)hipFree(kv.second.world_slots);
-                (void)hipFree(kv.second.job_counter); (void)hipFree(kv.second.counters);
+                free_workspace(kv.second);
             }
             (void)hipGetLastError();
             scene->workspaces.clear();
@@ -201,41 +218,53 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         Workspace &w = scene->workspaces[stream];
         const size_t need_att = ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double); // + a light's emitted colour
         if (need_att / sizeof(double) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the attenuation stack's 32-bit indices");
-        size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
-        if (w.att_bytes < need_att || w.sample_bytes < need_samples) HIP_TRY(hipStreamSynchronize(stream));
-        if (w.att_bytes < need_att) {
-            if (w.att_stack) HIP_TRY(hipFree(w.att_stack));
-            w.att_stack = nullptr; w.att_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&w.att_stack, need_att));
-            w.att_bytes = need_att;
-        }
         const size_t need_world = (size_t)6 * n_threads * sizeof(double);
-        if (w.world_bytes < need_world) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (w.world_slots) HIP_TRY(hipFree(w.world_slots));
-            w.world_slots = nullptr; w.world_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&w.world_slots, need_world));
-            w.world_bytes = need_world;
-        }
-        if (w.sample_bytes < need_samples) {
-            if (w.samples) HIP_TRY(hipFree(w.samples));
-            w.samples = nullptr; w.sample_bytes = 0;
-            // a device short of memory gets a smaller chunk (more launches), not an error
-            for (;;) {
-                const hipError_t e = hipMalloc((void **)&w.samples, need_samples);
-                if (e == hipSuccess) break;
-                (void)hipGetLastError();
-                w.samples = nullptr;
-                if (e != hipErrorOutOfMemory || chunk <= 1)
-                    return fail(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("rt_render: sample buffer: ") + hipGetErrorString(e));
-                chunk = (chunk + 1) / 2;
-                need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+        if (pipelined && !w.aux[0]) {
+            for (int h = 0; h < 2; ++h) {
+                HIP_TRY(hipStreamCreateWithFlags(&w.aux[h], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&w.ev_sum[h], hipEventDisableTiming));
             }
-            w.sample_bytes = need_samples;
-        } else if (w.sample_bytes < (size_t)bytes_per_sample_row * (size_t)chunk) {
-            chunk = (int64_t)(w.sample_bytes / (size_t)bytes_per_sample_row);
+            HIP_TRY(hipEventCreateWithFlags(&w.ev_start, hipEventDisableTiming));
         }
-        if (!w.job_counter) HIP_TRY(hipMalloc((void **)&w.job_counter, sizeof(uint32_t)));
+        // (every earlier launch on this stream ends with the stream waiting for the internal ones: draining it drains them)
+        bool drained = false;
+        auto drain = [&]() -> int { if (!drained) { HIP_TRY(hipStreamSynchronize(stream)); drained = true; } return RT_OK; };
+        for (int h = 0; h < (pipelined ? 2 : 1); ++h) {
+            LaunchScratch &x = w.half[h];
+            if (x.att_bytes < need_att) {
+                if ((rc = drain()) != RT_OK) return rc;
+                if (x.att_stack) HIP_TRY(hipFree(x.att_stack));
+                x.att_stack = nullptr; x.att_bytes = 0;
+                HIP_TRY(hipMalloc((void **)&x.att_stack, need_att));
+                x.att_bytes = need_att;
+            }
+            if (x.world_bytes < need_world) {
+                if ((rc = drain()) != RT_OK) return rc;
+                if (x.world_slots) HIP_TRY(hipFree(x.world_slots));
+                x.world_slots = nullptr; x.world_bytes = 0;
+                HIP_TRY(hipMalloc((void **)&x.world_slots, need_world));
+                x.world_bytes = need_world;
+            }
+            size_t need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+            if (x.sample_bytes < need_samples) {
+                if ((rc = drain()) != RT_OK) return rc;
+                if (x.samples) HIP_TRY(hipFree(x.samples));
+                x.samples = nullptr; x.sample_bytes = 0;
+                // a device short of memory gets a smaller chunk (more launches), not an error
+                for (;;) {
+                    const hipError_t e = hipMalloc((void **)&x.samples, need_samples);
+                    if (e == hipSuccess) break;
+                    (void)hipGetLastError();
+                    x.samples = nullptr;
+                    if (e != hipErrorOutOfMemory || chunk <= 1)
+                        return fail(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("rt_render: sample buffer: ") + hipGetErrorString(e));
+                    chunk = (chunk + 1) / 2;
+                    need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+                }
+                x.sample_bytes = need_samples;
+            }
+            if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, sizeof(uint32_t)));
+        }
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
         ws = w;
     }
@@ -246,9 +275,6 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
     K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
     K.out = d_out;
-    K.samples = ws.samples;
-    K.att_stack = ws.att_stack;
-    K.job_counter = ws.job_counter;
     K.counters = counted ? ws.counters : nullptr;
     K.cam = *camera;
     K.seed_mixed = host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
@@ -262,7 +288,6 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
-    K.world_slots = ws.world_slots;
     K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
@@ -277,9 +302,21 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
     }
 
+    // Launch k renders samples [sb, sb + ns) into its scratch set's sample buffer; sum_samples_kernel then adds them onto `out`
+    // in sample order.  Pipelined: launch k runs on internal stream k % 2; its summation waits for launch k - 1's (the sums
+    // stay in order) while the render kernel of launch k + 1, on the other stream, takes the CUs that launch k's tail frees.
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(ws.ev_start, stream));
+        for (int h = 0; h < 2; ++h) HIP_TRY(hipStreamWaitEvent(ws.aux[h], ws.ev_start, 0));
+    }
     const unsigned sum_grid = (unsigned)((n_local * 64 + 255) / 256);
-    for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk) {
+    int64_t k = 0;
+    for (int64_t sb = p.sample_begin; sb < p.sample_end; sb += chunk, ++k) {
         const int64_t ns = (p.sample_end - sb) < chunk ? (p.sample_end - sb) : chunk;
+        const int h = pipelined ? (int)(k & 1) : 0;
+        const hipStream_t s = pipelined ? ws.aux[h] : stream;
+        const LaunchScratch &x = ws.half[h];
+        K.samples = x.samples; K.att_stack = x.att_stack; K.job_counter = x.job_counter; K.world_slots = x.world_slots;
         K.sample_begin = (int32_t)sb;
         K.n_samples = (uint32_t)ns;
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
@@ -297,15 +334,18 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             K.grab_taper = tn.grab_taper > 0 ? 1.0f / (float)(waves * tn.grab_taper) : 1.0f; // (default 8, tools/sweep_grabs.sh)
         }
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
-        HIP_TRY(hipMemsetAsync(ws.job_counter, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(x.job_counter, 0, sizeof(uint32_t), s));
         {
             void *args[] = {(void *)&K};
-            HIP_TRY(hipLaunchKernel(path_kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered, aux_in_lds(scene, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, stream));
+            HIP_TRY(hipLaunchKernel(path_kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered, aux_in_lds(scene, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, s));
         }
         HIP_TRY(hipGetLastError());
-        launch_sum_samples(K, sum_grid, stream);
+        if (pipelined && k > 0) HIP_TRY(hipStreamWaitEvent(s, ws.ev_sum[h ^ 1], 0));
+        launch_sum_samples(K, sum_grid, s);
         HIP_TRY(hipGetLastError());
+        if (pipelined) HIP_TRY(hipEventRecord(ws.ev_sum[h], s));
     }
+    if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
 
     if (counted) {
         unsigned long long host[COUNTER_WORDS];

@@ -26,7 +26,10 @@ int fail(int status, const std::string &msg); // sets rt_last_error() of the cal
                                std::string(#expr) + ": " + hipGetErrorString(_e));                             \
     } while (0)
 
-struct Workspace {
+// Per-launch scratch.  A frame that needs several launches (sample sub-ranges, bounded by the sample buffer) alternates between
+// two such sets on two internal streams, so that the next launch's workgroups move in as the current one's drain (its tail)
+// instead of waiting behind its per-pixel summation.
+struct LaunchScratch {
     double *att_stack = nullptr;
     size_t att_bytes = 0;
     double *world_slots = nullptr; // [6][n_threads]
@@ -34,8 +37,14 @@ struct Workspace {
     double *samples = nullptr; // sample buffer of one launch
     size_t sample_bytes = 0;
     uint32_t *job_counter = nullptr;
+};
+struct Workspace {
+    LaunchScratch half[2];
+    hipStream_t aux[2] = {nullptr, nullptr};      // created on first use
+    hipEvent_t ev_start = nullptr, ev_sum[2] = {nullptr, nullptr};
     unsigned long long *counters = nullptr;
 };
+void free_workspace(Workspace &w);
 
 // Scheduler knobs (64ths of the live lanes a deferred stage must have queued / the box loop needs to keep running).
 // The best values depend on the stage mix, so there is one preset per kernel instantiation, each picked with
@@ -53,6 +62,7 @@ struct Tuning {
     int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
+    int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
     int grab_taper = 8;    // guided hand-out: a grab takes at most 1 / (waves x this) of the jobs left (RT_GRAB_TAPER; 0: off; tools/sweep_grabs.sh)
     OrderedOptions ordered_options;
     size_t sample_buffer_bytes = (size_t)2 << 30; // per-(scene, stream) sample buffer at most (halved on out-of-memory)

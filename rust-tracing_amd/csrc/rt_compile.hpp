@@ -122,9 +122,19 @@ class Compiler {
         if (d_.n_perlins) out_.perlins.assign(d_.perlins, d_.perlins + d_.n_perlins);
         for (int32_t i = 0; i < d_.n_images; ++i) {
             const rt_image &im = d_.images[i];
-            ImageRef r{(uint32_t)im.width, (uint32_t)im.height, (uint64_t)out_.texels.size()};
-            const size_t bytes = (size_t)im.width * (size_t)im.height * 3u;
-            out_.texels.insert(out_.texels.end(), im.rgb, im.rgb + bytes);
+            if (im.width <= 0 || im.height <= 0 || !im.rgb) throw CompileError(RT_ERR_INVALID_ARGUMENT, "image without texels");
+            const uint32_t tiles_x = ((uint32_t)im.width + TEXEL_TILE - 1u) / TEXEL_TILE, tiles_y = ((uint32_t)im.height + TEXEL_TILE - 1u) / TEXEL_TILE;
+            ImageRef r{};
+            r.width = (uint32_t)im.width; r.height = (uint32_t)im.height; r.tiles_x = tiles_x; r.offset = (uint64_t)out_.texels.size();
+            // row-major RGB8 (rt_image) -> 8x8 tiles (rt_layout.h ImageRef); padding texels are never addressed
+            out_.texels.resize(out_.texels.size() + (size_t)tiles_x * tiles_y * TEXEL_TILE * TEXEL_TILE * 3u, 0);
+            uint8_t *dst = out_.texels.data() + r.offset;
+            for (uint32_t j = 0; j < r.height; ++j)
+                for (uint32_t i = 0; i < r.width; ++i) {
+                    const uint8_t *src = im.rgb + ((size_t)j * r.width + i) * 3u;
+                    uint8_t *px = dst + texel_index(tiles_x, i, j) * 3u;
+                    px[0] = src[0]; px[1] = src[1]; px[2] = src[2];
+                }
             // keep every image 16-byte aligned in the pool
             out_.texels.resize((out_.texels.size() + 15u) & ~(size_t)15u, 0);
             out_.images.push_back(r);

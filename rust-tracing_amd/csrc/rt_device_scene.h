@@ -136,7 +136,8 @@ template <bool COUNT> RT_DEV V3 texture_value(const KParams &P, const rt_texture
         const double vc = 1.0 - clamp01(v);
         const uint32_t i = f64_as_u32(uc * (double)(im.width - 1u));
         const uint32_t j = f64_as_u32(vc * (double)(im.height - 1u));
-        const uint8_t *px = P.texels + im.offset + ((size_t)j * im.width + i) * 3u;
+        // (8x8 texel tiles, rt_layout.h ImageRef: the same texel the reference's row-major index names)
+        const uint8_t *px = P.texels + im.offset + (((size_t)(j >> 3) * im.tiles_x + (i >> 3)) * 64u + ((j & 7u) << 3) + (i & 7u)) * 3u;
         return v3(P.srgb_lut[px[0]], P.srgb_lut[px[1]], P.srgb_lut[px[2]]);
     }
     // RT_TEXTURE_NOISE, src/texture.rs:107-110

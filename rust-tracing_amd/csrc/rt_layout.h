@@ -130,10 +130,21 @@ struct alignas(16) Medium {
                          // for NK_MEDIUM_SPHERE: index of the boundary sphere
 };
 
+// Texels are stored in 8x8 tiles (a tile = 192 consecutive bytes, tiles row-major, the image padded to whole tiles): the
+// lookups of neighbouring hit points — the reference indexes a row-major image (src/texture.rs:83-92) — land in one or two
+// cache lines instead of one line per row.  texel (i, j) lives at offset + ((j / 8 * tiles_x + i / 8) * 64 + (j % 8) * 8 + i % 8) * 3.
+constexpr uint32_t TEXEL_TILE = 8;
 struct alignas(16) ImageRef {
     uint32_t width, height;
-    uint64_t offset; // byte offset of the first texel in the texel pool
+    uint32_t tiles_x; // tiles per tile row
+    uint32_t _pad;
+    uint64_t offset;  // byte offset of the first tile in the texel pool
+    uint64_t _pad2;
 };
+static_assert(sizeof(ImageRef) == 32, "ImageRef must be 32 bytes");
+inline uint64_t texel_index(uint32_t tiles_x, uint32_t i, uint32_t j) {
+    return ((uint64_t)(j / TEXEL_TILE) * tiles_x + i / TEXEL_TILE) * (TEXEL_TILE * TEXEL_TILE) + (j % TEXEL_TILE) * TEXEL_TILE + i % TEXEL_TILE;
+}
 
 // prim id stored with the closest hit: kind in the top 2 bits
 constexpr uint32_t PRIM_NONE = 0xffffffffu;

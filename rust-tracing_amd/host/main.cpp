@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
     bool live = false;
     std::string output = "output";
     SceneOptions so;
-    so.earth_image = "synthetic:6400x3200";
+    so.earth_image = "assets/earth-large.jpg"; // the reference's default (src/main.rs:179,:591); --earth synthetic:WxH needs no file
     RenderOptions ro;
     uint64_t scene_seed = 1;
 

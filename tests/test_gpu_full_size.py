@@ -8,7 +8,10 @@ import numpy as np
 import pytest
 import torch
 
+import scene_cases
+
 pytestmark = pytest.mark.gpu
+EARTH_LARGE = str(scene_cases.ASSETS / "earth-large.jpg")  # the reference's 6400x3200 asset (assets/README.md)
 
 
 def digest(t):
@@ -91,7 +94,7 @@ def test_c3_cornell_600x600_1000spp_depth50(rt, gpu):
 def test_c4_final_scene_800x800_depth40(rt, gpu):
     """BASELINE.json configs[3] at its full image size; 400 of the 5000 spp keep the test to a few seconds
     (cost and every code path are the same per sample)."""
-    hs = rt.HostScene(8, scene_seed=1, width=800, aspect=1.0, spp=400, depth=40, earth_image="synthetic:6400x3200")
+    hs = rt.HostScene(8, scene_seed=1, width=800, aspect=1.0, spp=400, depth=40, earth_image=EARTH_LARGE)
     ds = rt.DeviceScene(hs)
     st = ds.stats()
     assert st["n_media"] == 2 and st["n_instances"] == 1 and st["image_bytes"] == 6400 * 3200 * 3
@@ -111,7 +114,7 @@ def test_c5_final_scene_1600x1600_depth50_in_8_shards(rt, gpu):
     10000 spp keep it to seconds.  The sample buffer is capped at 64 MiB for this scene, so the whole frame (61 MB per sample
     row) runs one sample per launch and every shard (7.7 MB per row) fills and drains its buffer six times: chunked launches,
     chained sample ranges and the shard layout all have to agree on one frame."""
-    hs = rt.HostScene(8, scene_seed=1, width=1600, aspect=1.0, spp=48, depth=50, earth_image="synthetic:6400x3200")
+    hs = rt.HostScene(8, scene_seed=1, width=1600, aspect=1.0, spp=48, depth=50, earth_image=EARTH_LARGE)
     assert (hs.width, hs.height, hs.camera.max_depth) == (1600, 1600, 50)
     ds = rt.DeviceScene(hs)                                     # default sample buffer (2 GiB): 34 spp per launch
     small = rt.DeviceScene(hs, sample_buffer_bytes=64 << 20)    # 1 spp per launch whole, 8 spp per launch per shard
