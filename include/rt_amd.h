@@ -327,6 +327,13 @@ int rt_resolve_rgb8_values_device(int64_t n_values, int32_t spp, const double *d
 int rt_tiles_to_frame_rgb8_device(int32_t width, int32_t height, int32_t shard_count, const uint8_t *d_gathered,
                                   uint8_t *d_frame, void *hip_stream);
 
+/* Device memory for hosts that do not link the HIP runtime themselves (the Rust binding, host/renderer.cpp): the buffers
+ * rt_render_device, the gather and the frame-end kernels work on.  rt_device_download copies to host memory and returns when
+ * the copy — and everything enqueued on hip_stream before it — is done. */
+int rt_device_malloc(int device, int64_t bytes, void **out_device_ptr);
+int rt_device_free(int device, void *device_ptr);
+int rt_device_download(int device, void *dst_host, const void *src_device, int64_t bytes, void *hip_stream);
+
 /* ---- frame-end gather over RCCL / xGMI ----------------------------------------------------------
  * One communicator handle per rank (= per GPU).  Create it either
  *   - one process per GPU: rank 0 calls rt_comm_get_unique_id and hands the 128 bytes to the other ranks by whatever

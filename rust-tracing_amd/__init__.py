@@ -210,6 +210,9 @@ RT_AMD_SYMBOLS = {
     "rt_scene_create_ex": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_resolve_rgb8_values_device": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_tiles_to_frame_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_device_malloc": (C.c_int, [C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rt_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "rt_device_download": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rt_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "rt_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rt_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),

@@ -24,6 +24,8 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_OVERLAP", overlap);
+    env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
+    env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
     if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
@@ -193,15 +195,30 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
     const int threads = block_threads(scene, lds);
     const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
-    const size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
+    size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
+    // The pool kernel (rt_pool_kernel.hip: paths move between traversal lanes and full-width shading rounds through an LDS pool)
+    // renders ordered scenes that live in the LDS whole, if what the scene leaves of the LDS holds a pool worth having.
+    uint32_t pool_slots = 0, pool_off = 0;
+    if (!counted && tn.pool != 0 && scene->ordered && lds == 3 && p.max_depth < 65536 && tn.pool_service >= 1 && tn.pool_service * 64 < threads) {
+        pool_off = (uint32_t)align16(prof_offset(scene, lds));
+        const size_t room = LDS_BUDGET_BYTES > pool_off + pool_ctl_bytes() ? LDS_BUDGET_BYTES - pool_off - pool_ctl_bytes() : 0;
+        size_t words = room / (POOL_SLOT_BYTES * 64);
+        if (words > 16) words = 16;
+        if (words >= 4 && words * 64 + (size_t)threads < 65536) {
+            pool_slots = (uint32_t)(words * 64);
+            dyn_lds = pool_off + pool_ctl_bytes() + (size_t)pool_slots * POOL_SLOT_BYTES;
+        }
+    }
+    const bool pooled = pool_slots != 0;
     // persistent grid: every resident wave pulls jobs until none are left
-    int64_t grid = (int64_t)scene->n_cus * bpc;
-    const int64_t waves_per_block = threads / 64;
+    int64_t grid = (int64_t)scene->n_cus * (pooled ? 1 : bpc);
+    const int64_t waves_per_block = pooled ? tn.pool_service : threads / 64; // (waves that hand out jobs)
     // (a small frame gets a smaller grid: a wave with fewer than MIN_JOBS_PER_WAVE jobs costs more to start than it adds)
     const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_WAVE * waves_per_block - 1) / (MIN_JOBS_PER_WAVE * waves_per_block);
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
-    const uint32_t n_threads = (uint32_t)(grid * threads);
+    // (pool kernel: the attenuation stack has one column per path id: slots + threads of every workgroup)
+    const uint32_t n_threads = (uint32_t)(grid * (threads + (int64_t)pool_slots));
 
     Workspace ws;
     {
@@ -263,7 +280,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
                 }
                 x.sample_bytes = need_samples;
             }
-            if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, sizeof(uint32_t)));
+            if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, 2 * sizeof(uint32_t))); // [1]: the pool kernel's give-up flag
         }
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
         ws = w;
@@ -301,6 +318,11 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : (scene->ordered ? tn.ordered_general : tn.general)));
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
     }
+    if (pooled) { // (the pool kernel's thresholds are lane counts)
+        K.pool_off = pool_off; K.pool_slots = pool_slots; K.pool_service_waves = (uint32_t)tn.pool_service;
+        K.pool_patience = (uint32_t)tn.pool_patience; K.pool_full = (uint32_t)tn.pool_full;
+        K.th_prim = (uint32_t)tn.pool_th[0]; K.th_other = (uint32_t)tn.pool_th[1]; K.th_shade = (uint32_t)tn.pool_th[2]; K.th_box = (uint32_t)tn.pool_th[3];
+    }
 
     // Launch k renders samples [sb, sb + ns) into its scratch set's sample buffer; sum_samples_kernel then adds them onto `out`
     // in sample order.  Pipelined: launch k runs on internal stream k % 2; its summation waits for launch k - 1's (the sums
@@ -334,10 +356,13 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             K.grab_taper = tn.grab_taper > 0 ? 1.0f / (float)(waves * tn.grab_taper) : 1.0f; // (default 8, tools/sweep_grabs.sh)
         }
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
-        HIP_TRY(hipMemsetAsync(x.job_counter, 0, sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(x.job_counter, 0, pooled ? 2 * sizeof(uint32_t) : sizeof(uint32_t), s));
         {
             void *args[] = {(void *)&K};
-            HIP_TRY(hipLaunchKernel(path_kernel_for(lds, counted, kernel_features_for(scene->features, lds, scene->ordered), scene->ordered, aux_in_lds(scene, lds)), dim3((unsigned)grid), dim3(threads), args, dyn_lds, s));
+            const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
+            const void *fn = pooled ? pool_kernel_for(kf, aux_in_lds(scene, lds)) : path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds));
+            if (pooled && dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+            HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, dyn_lds, s));
         }
         HIP_TRY(hipGetLastError());
         if (pipelined && k > 0) HIP_TRY(hipStreamWaitEvent(s, ws.ev_sum[h ^ 1], 0));
@@ -346,6 +371,14 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         if (pipelined) HIP_TRY(hipEventRecord(ws.ev_sum[h], s));
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
+    if (pooled && tn.pool_check != 0) { // RT_POOL_CHECK=1 (tests): wait, and turn the pool kernel's give-up flag into an error
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int h = 0; h < (pipelined ? 2 : 1); ++h) {
+            uint32_t flag = 0;
+            HIP_TRY(hipMemcpy(&flag, ws.half[h].job_counter + 1, sizeof flag, hipMemcpyDeviceToHost));
+            if (flag) return fail(RT_ERR_HIP, "rt_render: the pool kernel stopped itself (flag " + std::to_string(flag) + ")");
+        }
+    }
 
     if (counted) {
         unsigned long long host[COUNTER_WORDS];
@@ -684,20 +717,59 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, const rt_render_pa
     return RT_OK;
 }
 
+// the frame-end kernels run on the device that owns the buffers, whichever device the calling thread had selected
+static int select_device_of(const void *device_ptr, const char *who) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string(who) + ": not a device pointer");
+    }
+    HIP_TRY(hipSetDevice(attr.device));
+    return RT_OK;
+}
+
 int rt_tiles_to_frame_device(int32_t width, int32_t height, int32_t shard_count, const double *d_gathered, double *d_frame,
                              void *hip_stream) {
     if (!d_gathered || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
         return fail(RT_ERR_INVALID_ARGUMENT, "rt_tiles_to_frame_device: bad argument");
+    if (int rc = select_device_of(d_frame, "rt_tiles_to_frame_device")) return rc;
     const int64_t stride = rt_out_size(width, height, RT_OUT_TILES, 0, shard_count);
     const int32_t tiles_x = (width + RT_TILE_W - 1) / RT_TILE_W;
     launch_tiles_to_frame(width, height, tiles_x, shard_count, stride, d_gathered, d_frame, (hipStream_t)hip_stream);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
+int rt_device_malloc(int device, int64_t bytes, void **out_device_ptr) {
+    if (!out_device_ptr || bytes <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_device_malloc: bad argument");
+    *out_device_ptr = nullptr;
+    if (device < 0 || device >= rt_device_count()) return fail(RT_ERR_NO_DEVICE, "rt_device_malloc: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out_device_ptr, (size_t)bytes));
+    return RT_OK;
+}
+
+int rt_device_free(int device, void *device_ptr) {
+    if (!device_ptr) return RT_OK;
+    if (device < 0 || device >= rt_device_count()) return fail(RT_ERR_NO_DEVICE, "rt_device_free: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(device_ptr));
+    return RT_OK;
+}
+
+int rt_device_download(int device, void *dst_host, const void *src_device, int64_t bytes, void *hip_stream) {
+    if (!dst_host || !src_device || bytes <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_device_download: bad argument");
+    if (device < 0 || device >= rt_device_count()) return fail(RT_ERR_NO_DEVICE, "rt_device_download: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(dst_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    return RT_OK;
+}
+
 int rt_tiles_to_frame_rgb8_device(int32_t width, int32_t height, int32_t shard_count, const uint8_t *d_gathered, uint8_t *d_frame,
                                   void *hip_stream) {
     if (!d_gathered || !d_frame || width <= 0 || height <= 0 || shard_count <= 0)
         return fail(RT_ERR_INVALID_ARGUMENT, "rt_tiles_to_frame_rgb8_device: bad argument");
+    if (int rc = select_device_of(d_frame, "rt_tiles_to_frame_rgb8_device")) return rc;
     const int64_t stride = rt_out_size(width, height, RT_OUT_TILES, 0, shard_count);
     const int32_t tiles_x = (width + RT_TILE_W - 1) / RT_TILE_W;
     launch_tiles_to_frame_rgb8(width, height, tiles_x, shard_count, stride, d_gathered, d_frame, (hipStream_t)hip_stream);
@@ -707,6 +779,7 @@ int rt_tiles_to_frame_rgb8_device(int32_t width, int32_t height, int32_t shard_c
 
 int rt_resolve_rgb8_values_device(int64_t n_values, int32_t spp, const double *d_sum, uint8_t *d_rgb8, void *hip_stream) {
     if (!d_sum || !d_rgb8 || n_values <= 0 || spp <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "rt_resolve_rgb8_values_device: bad argument");
+    if (int rc = select_device_of(d_rgb8, "rt_resolve_rgb8_values_device")) return rc;
     launch_resolve_rgb8(n_values, 1.0 / (double)spp, d_sum, d_rgb8, (hipStream_t)hip_stream);
     HIP_TRY(hipGetLastError());
     return RT_OK;

@@ -62,6 +62,11 @@ struct Tuning {
     int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
+    int pool = 1;          // 1: ordered LDS-resident scenes render with the pool kernel (ray compaction across stages; RT_POOL)
+    int pool_check = 0;    // ... 1: every render waits for its launches and reports a launch that flagged itself (RT_POOL_CHECK; tests)
+    int pool_service = 2;  // ... service waves per workgroup (RT_POOL_SERVICE)
+    int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)
+    int pool_patience = 2, pool_full = 64; // ... idle polls before a service wave takes a partial word; entries that make a word 'full'
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
     int grab_taper = 8;    // guided hand-out: a grab takes at most 1 / (waves x this) of the jobs left (RT_GRAB_TAPER; 0: off; tools/sweep_grabs.sh)
     OrderedOptions ordered_options;

@@ -73,6 +73,11 @@ struct KParams {
     uint32_t lds_stack_off;
     uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)
     uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
+    // pool kernel (rt_pool_kernel.hip): the path-slot pool in the LDS and the split of the workgroup's waves
+    uint32_t pool_off, pool_slots;  // control block + slots (a multiple of 64)
+    uint32_t pool_service_waves;    // the first so many waves shade and end paths, the others walk
+    uint32_t pool_patience;         // idle polls after which a service wave takes a word that is not full
+    uint32_t pool_full;             // entries a word must hold to be taken at once
 };
 
 // What a scene can contain.  A kernel instantiated without a feature has that code compiled out, which matters for
@@ -112,6 +117,9 @@ constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quad
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
 int kernel_threads_for(uint32_t kernel_features, int lds); // workgroup size of that instantiation
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux);
+const void *pool_kernel_for(uint32_t feat, bool aux); // ordered, LDS-resident scenes (lds level 3)
+size_t pool_ctl_bytes();
+constexpr size_t POOL_SLOT_BYTES = 96;
 
 // launches of the small kernels (all asynchronous on `stream`; errors through hipGetLastError)
 void launch_sum_samples(const KParams &K, unsigned grid, hipStream_t stream);

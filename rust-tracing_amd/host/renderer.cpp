@@ -33,6 +33,54 @@ std::vector<double> render_sums(const Camera &camera, const Hittable &world, con
     std::vector<double> sums((size_t)cam.image_width * (size_t)cam.image_height * 3u, 0.0);
     const int spp = cam.samples_per_pixel;
     const int pass = opt.progressive_spp > 0 ? opt.progressive_spp : spp;
+    const int32_t w = cam.image_width, h = cam.image_height;
+
+    // Device route (include/rt_amd.h "frame-end gather"): every device renders its tiles (k % ngpu == g) into its own tile buffer in
+    // HBM; at the end of a pass ONE grouped RCCL exchange brings the buffers to device 0 over xGMI, which reassembles the frame and
+    // hands it to the host in one copy.  If RCCL cannot be loaded the frame travels through host memory instead (below).
+    std::vector<rt_comm *> comms((size_t)ngpu, nullptr);
+    const bool device_route = rt_comm_create_all(ngpu, nullptr, comms.data()) == RT_OK;
+    if (device_route) {
+        const int64_t stride = rt_out_size(w, h, RT_OUT_TILES, 0, ngpu);
+        std::vector<void *> tiles((size_t)ngpu, nullptr);
+        void *gathered = nullptr, *frame = nullptr;
+        auto cleanup = [&]() {
+            for (int g = 0; g < ngpu; ++g) { rt_device_free(g, tiles[(size_t)g]); rt_comm_destroy(comms[(size_t)g]); }
+            rt_device_free(0, gathered); rt_device_free(0, frame);
+            destroy_all();
+        };
+        bool ok = rt_device_malloc(0, stride * ngpu * (int64_t)sizeof(double), &gathered) == RT_OK &&
+                  rt_device_malloc(0, (int64_t)sums.size() * (int64_t)sizeof(double), &frame) == RT_OK;
+        for (int g = 0; g < ngpu && ok; ++g) ok = rt_device_malloc(g, stride * (int64_t)sizeof(double), &tiles[(size_t)g]) == RT_OK;
+        if (!ok) { const std::string msg = rt_last_error(); cleanup(); throw std::runtime_error("render: " + msg); }
+        for (int begin = 0; begin < spp; begin += pass) {
+            const int end = begin + pass < spp ? begin + pass : spp;
+            std::vector<std::string> errors((size_t)ngpu);
+            std::vector<std::thread> workers;
+            for (int g = 0; g < ngpu; ++g) {
+                workers.emplace_back([&, g]() { // one host thread per device: render, then this rank's part of the gather
+                    rt_render_params p{};
+                    p.seed = opt.seed; p.sample_begin = begin; p.sample_end = end; p.max_depth = cam.max_depth;
+                    p.accumulate = begin > 0 ? 1 : 0; // the tile buffers keep the running sums between passes
+                    p.shard_index = g; p.shard_count = ngpu; p.out_layout = RT_OUT_TILES; p.device = g;
+                    if (rt_render_device(scenes[(size_t)g], &cam, &p, static_cast<double *>(tiles[(size_t)g]), nullptr) != RT_OK ||
+                        rt_gather_tiles_device(comms[(size_t)g], w, h, 8, tiles[(size_t)g], g == 0 ? gathered : nullptr, 0, nullptr) != RT_OK)
+                        errors[(size_t)g] = rt_last_error();
+                });
+            }
+            for (auto &t : workers) t.join();
+            for (const auto &e : errors)
+                if (!e.empty()) { cleanup(); throw std::runtime_error("render: " + e); }
+            if (rt_tiles_to_frame_device(w, h, ngpu, static_cast<const double *>(gathered), static_cast<double *>(frame), nullptr) != RT_OK ||
+                rt_device_download(0, sums.data(), frame, (int64_t)sums.size() * (int64_t)sizeof(double), nullptr) != RT_OK) {
+                const std::string msg = rt_last_error(); cleanup(); throw std::runtime_error("render: " + msg);
+            }
+            if (on_pass) on_pass(sums, end);
+        }
+        cleanup();
+        return sums;
+    }
+
     for (int begin = 0; begin < spp; begin += pass) {
         const int end = begin + pass < spp ? begin + pass : spp;
         std::vector<std::string> errors((size_t)ngpu);

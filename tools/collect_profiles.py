@@ -1,13 +1,22 @@
 #!/usr/bin/env python3
 """Condenses gpurun_out/prof/ (written by tools/profile_round.sh on the GPU box) into the tracked profiles/ files.
-Usage: python tools/collect_profiles.py <tag>      e.g. r01_ordered"""
-import csv, glob, json, shutil, sys
+Usage: python tools/collect_profiles.py <tag>      e.g. r02
+
+  profiles/<tag>_bench_<w>.json            bench.py's line per workload (c1..c4)
+  profiles/<tag>_<w>_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of `bench.py --workload <w>`
+  profiles/<tag>_<w>_pmc.json              SQ counters of the render kernel's dispatches of ONE frame (two --pmc passes) + derived
+                                           lane utilisation / wait share, and the HBM counters of their own passes
+  profiles/<tag>_stage_profile_<w>.txt     per-stage rounds / lanes / cycles of the instrumented kernel
+  profiles/hbm_traffic.json                per workload: HBM bytes of one frame (what bench.py prints as roofline.traffic)
+"""
+import csv, glob, json, shutil, subprocess, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "gpurun_out" / "prof"
 DST = ROOT / "profiles"
 tag = sys.argv[1]
+KERNEL = "path_kernel<false"  # the un-instrumented render kernel (bench.py's counting passes use path_kernel<true)
 
 
 def one(pattern):
@@ -16,50 +25,57 @@ def one(pattern):
     return Path(hits[-1])  # (gpurun merges into gpurun_out/ without clearing it: take the latest run's file)
 
 
-def counters(run, kernel_prefix="void (anonymous namespace)::path_kernel<false"):
-    """Sum of each counter over the dispatches of the un-instrumented render kernel (one per bench step)."""
+def counters(run):
+    """Sum of each counter over the render kernel's dispatches (one frame = one bench step: --steps 1 --warmup 0; a frame that
+    needs several launches has several dispatches)."""
     out, dispatches = {}, set()
     with open(one(f"{run}/*/*_counter_collection.csv")) as f:
         for row in csv.DictReader(f):
-            if row["Kernel_Name"].startswith(kernel_prefix):
+            if KERNEL in row["Kernel_Name"]:
                 out[row["Counter_Name"]] = out.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                 dispatches.add(row["Dispatch_Id"])
-                out["_kernel"] = row["Kernel_Name"].split("(")[1 if row["Kernel_Name"].startswith("void (") else 0]
                 out["_kernel"] = row["Kernel_Name"]
-                out["_vgprs"], out["_lds_bytes"], out["_scratch"] = row["VGPR_Count"], row["LDS_Block_Size"], row["Scratch_Size"]
-    out["_dispatches"] = len(dispatches)
+                out["_rocprof_vgpr_field"], out["_rocprof_lds_field"], out["_scratch"] = row["VGPR_Count"], row["LDS_Block_Size"], row["Scratch_Size"]
+    out["_dispatches_per_frame"] = len(dispatches)
     return out
 
 
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+hbm = {}
 for w in ("c1", "c2", "c3", "c4"):
     shutil.copy(SRC / f"bench_{w}.json", DST / f"{tag}_bench_{w}.json")
     if (SRC / f"stage_{w}.txt").exists():
         text = "\n".join(l for l in (SRC / f"stage_{w}.txt").read_text().splitlines() if "amdgpu.ids" not in l)
         (DST / f"{tag}_stage_profile_{w}.txt").write_text(text + "\n")
-shutil.copy(one("kt/*/*_kernel_stats.csv"), DST / f"{tag}_c2_kernel_stats.csv")
-
-fetch, write = counters("fetch"), counters("write")
-assert fetch["_dispatches"] == 1 and write["_dispatches"] == 1
-# MI355X_MICROARCH.md, HBM / rocprofv3: FETCH_SIZE and WRITE_SIZE are in KiB, each in its own pass; gfx950 reports half
-# of the bytes fetched (x2 correction)
-traffic = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
-hbm = {"c2": {"bytes_per_launch": traffic, "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
-              "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (separate --pmc passes; gfx950 FETCH_SIZE x2 correction; access "
-                         "widths here are 8 B per lane, outside the calibrated 16 B streaming case)",
-              "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-              "kernel": fetch["_kernel"], "tag": tag}}
+    shutil.copy(one(f"kt_{w}/*/*_kernel_stats.csv"), DST / f"{tag}_{w}_kernel_stats.csv")
+    fetch, write = counters(f"fetch_{w}"), counters(f"write_{w}")
+    # MI355X_MICROARCH.md, HBM / rocprofv3: FETCH_SIZE and WRITE_SIZE are in KiB, each in its own pass; gfx950 reports half
+    # of the bytes fetched (x2 correction)
+    traffic = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+    bench = json.load(open(SRC / f"bench_{w}.json"))
+    hbm[w] = {"bytes_per_launch": traffic, "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
+              "dispatches_per_frame": fetch["_dispatches_per_frame"],
+              "achieved_GBps": round(traffic / (bench["roofline"]["kernel_ms"] * 1e-3) / 1e9, 1),
+              "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, summed over the frame's render-kernel dispatches (separate --pmc passes; "
+                         "gfx950 FETCH_SIZE x2 correction; access widths here are 8 B per lane, outside the calibrated 16 B streaming case)",
+              "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --workload {w} --steps 1 --warmup 0 --no-cpu-baseline",
+              "kernel": fetch["_kernel"], "tag": f"{tag} ({commit})"}
+    if w == "c1":
+        continue
+    sq = {}
+    for run in (f"sq1_{w}", f"sq2_{w}"):
+        sq.update(counters(run))
+    sq["valu_lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64.0)
+    sq["wait_inst_any_share_of_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
+    sq["lds_bank_conflict_share_of_lds_active"] = sq["SQ_LDS_BANK_CONFLICT"] / max(1.0, sq["SQ_LDS_IDX_ACTIVE"])
+    sq["hbm_bytes_per_frame"] = traffic
+    sq["_note"] = (f"rocprofv3 --pmc (two passes of 8 SQ counters), the render kernel's dispatches of one frame of bench.py --workload {w}; "
+                   "tools/profile_round.sh.  _rocprof_vgpr_field is rocprofv3's VGPR_Count column — for this wave64 kernel half the "
+                   "allocated registers (56 <-> 112..119; the compiler's figure is in kernel_usage.txt) — and _rocprof_lds_field its "
+                   "LDS_Block_Size, the STATIC group segment only: the kernel's LDS is all dynamic (bench line: scene stats lds_bytes)")
+    (DST / f"{tag}_{w}_pmc.json").write_text(json.dumps(sq, indent=1) + "\n")
+    print(w, bench["value"], "Msamples/s; HBM", round(traffic / 1e9, 2), "GB/frame =", hbm[w]["achieved_GBps"], "GB/s; VALU lane utilisation",
+          round(sq["valu_lane_utilisation"], 3), "WAIT_INST_ANY share", round(sq["wait_inst_any_share_of_wave_cycles"], 3))
 (DST / "hbm_traffic.json").write_text(json.dumps(hbm, indent=1) + "\n")
-
-sq = {}
-for run in ("sq1", "sq2"):
-    c = counters(run)
-    assert c["_dispatches"] == 1
-    sq.update({k: v for k, v in c.items()})
-sq["valu_lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64.0)
-sq["wait_inst_any_share_of_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
-sq["_note"] = ("rocprofv3 --pmc (two passes of 8 SQ counters), one dispatch of the render kernel of bench.py's default workload "
-               "(C2, 480 M samples); tools/profile_round.sh")
-(DST / f"{tag}_c2_pmc.json").write_text(json.dumps(sq, indent=1) + "\n")
-b = json.load(open(SRC / "bench_c2.json"))
-print("c2", b["value"], "Msamples/s; HBM traffic per launch", traffic / 1e9, "GB;", "VALU lane utilisation", round(sq["valu_lane_utilisation"], 3),
-      "WAIT_INST_ANY share", round(sq["wait_inst_any_share_of_wave_cycles"], 3))
+if (SRC / "kernel_usage.txt").exists():
+    shutil.copy(SRC / "kernel_usage.txt", DST / f"{tag}_kernel_usage.txt")
