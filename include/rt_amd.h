@@ -273,6 +273,10 @@ typedef struct rt_scene_options {
     int32_t th_prim, th_other, th_shade, th_box, th_new; /* scheduler thresholds in 64ths of a wave's live lanes; -1: preset */
     int64_t sample_buffer_bytes; /* per-(scene, stream) sample buffer at most; <= 0: default (2 GiB).  A frame that needs
                                     more is rendered in several launches over sample sub-ranges (same result). */
+    int32_t pool;                /* -1 default (off); 1: render with the pool kernel where the scene allows it (LDS-resident, own
+                                    trees): paths move between walking lanes and full-width shading rounds through a slot pool in
+                                    the LDS (DESIGN.md "Ray compaction across stages"); 0: never */
+    int32_t _reserved;
 } rt_scene_options;
 void rt_scene_options_init(rt_scene_options *options);
 int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_options *options /* NULL: defaults */,

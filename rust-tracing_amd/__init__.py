@@ -169,7 +169,8 @@ class SceneCreateOptions(C.Structure):
     """rt_scene_options (per-scene options of rt_scene_create_ex)."""
     _fields_ = [("struct_size", C.c_uint32), ("walk", C.c_int32), ("leaf_max", C.c_int32), ("refit", C.c_int32),
                 ("use_lds", C.c_int32), ("th_prim", C.c_int32), ("th_other", C.c_int32), ("th_shade", C.c_int32),
-                ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64)]
+                ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("pool", C.c_int32),
+                ("_reserved", C.c_int32)]
 
 
 def scene_options(**kw) -> "SceneCreateOptions":

@@ -24,7 +24,7 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_OVERLAP", overlap);
-    env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
+    env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
@@ -158,6 +158,7 @@ Tuning effective_tuning(const rt_scene *scene) {
     for (int k = 0; k < 5; ++k)
         if (th[k] >= 0 && tn.forced[k] < 0) tn.forced[k] = th[k];
     if (o.sample_buffer_bytes > 0) tn.sample_buffer_bytes = (size_t)o.sample_buffer_bytes;
+    if (o.pool >= 0) tn.pool = o.pool;
     return tn;
 }
 
@@ -199,14 +200,36 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     // The pool kernel (rt_pool_kernel.hip: paths move between traversal lanes and full-width shading rounds through an LDS pool)
     // renders ordered scenes that live in the LDS whole, if what the scene leaves of the LDS holds a pool worth having.
     uint32_t pool_slots = 0, pool_off = 0;
+    bool pool_aux = aux_in_lds(scene, lds);
+    uint32_t pool_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     if (!counted && tn.pool != 0 && scene->ordered && lds == 3 && p.max_depth < 65536 && tn.pool_service >= 1 && tn.pool_service * 64 < threads) {
-        pool_off = (uint32_t)align16(prof_offset(scene, lds));
-        const size_t room = LDS_BUDGET_BYTES > pool_off + pool_ctl_bytes() ? LDS_BUDGET_BYTES - pool_off - pool_ctl_bytes() : 0;
-        size_t words = room / (POOL_SLOT_BYTES * 64);
-        if (words > 16) words = 16;
+        // the pool takes what the scene, the stacks and the sequence leave; the small tables stay in the LDS only if the pool
+        // still gets POOL_WANT_WORDS words (a pool much smaller than the number of walking lanes starves them)
+        auto layout = [&](bool with_aux, uint32_t &world_off) {
+            const size_t a_end = aux_offset(scene, lds) + (with_aux ? scene->aux_bytes : 0u);
+            const bool world = scene->has_instances && align16(a_end) + world_bytes(scene, lds) + pool_ctl_bytes() + 4 * 64 * POOL_SLOT_BYTES <= LDS_BUDGET_BYTES;
+            world_off = world ? (uint32_t)align16(a_end) : 0xffffffffu;
+            return align16(align16(a_end) + (world ? world_bytes(scene, lds) : 0u));
+        };
+        auto words_at = [&](size_t off) {
+            const size_t room = LDS_BUDGET_BYTES > off + pool_ctl_bytes() ? LDS_BUDGET_BYTES - off - pool_ctl_bytes() : 0;
+            const size_t wds = room / (POOL_SLOT_BYTES * 64);
+            return wds > 16 ? (size_t)16 : wds;
+        };
+        uint32_t w_off = 0xffffffffu;
+        size_t off = layout(pool_aux, w_off), words = words_at(off);
+        if (pool_aux && (tn.pool_aux == 0 || (tn.pool_aux < 0 && words < (size_t)tn.pool_want_words))) {
+            uint32_t w_off2 = 0xffffffffu;
+            const size_t off2 = layout(false, w_off2), words2 = words_at(off2);
+            if (words2 > words) { pool_aux = false; off = off2; words = words2; w_off = w_off2; }
+        }
         if (words >= 4 && words * 64 + (size_t)threads < 65536) {
+            pool_off = (uint32_t)off;
             pool_slots = (uint32_t)(words * 64);
+            pool_world_off = w_off;
             dyn_lds = pool_off + pool_ctl_bytes() + (size_t)pool_slots * POOL_SLOT_BYTES;
+        } else {
+            pool_aux = aux_in_lds(scene, lds);
         }
     }
     const bool pooled = pool_slots != 0;
@@ -285,14 +308,18 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
         ws = w;
     }
-    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
+    if (counted || (pooled && tn.pool_prof != 0)) {
+        if (!counted) HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemsetAsync(ws.counters, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
+        if (!counted) HIP_TRY(hipStreamSynchronize(stream));
+    }
 
     KParams K{};
     K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
     K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
     K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
     K.out = d_out;
-    K.counters = counted ? ws.counters : nullptr;
+    K.counters = (counted || (pooled && tn.pool_prof != 0)) ? ws.counters : nullptr;
     K.cam = *camera;
     K.seed_mixed = host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
     K.n_nodes = scene->n_nodes;
@@ -305,7 +332,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
-    K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
+    K.lds_world_off = pool_world_off;
     K.box_extent = scene->box_extent;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
@@ -360,7 +387,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         {
             void *args[] = {(void *)&K};
             const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-            const void *fn = pooled ? pool_kernel_for(kf, aux_in_lds(scene, lds)) : path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds));
+            const void *fn = pooled ? pool_kernel_for(kf, pool_aux, tn.pool_prof != 0) : path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds));
             if (pooled && dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, dyn_lds, s));
         }
@@ -371,6 +398,18 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         if (pipelined) HIP_TRY(hipEventRecord(ws.ev_sum[h], s));
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
+    if (pooled && tn.pool_prof != 0) { // RT_POOL_PROF=1: where the pool kernel's waves spent their cycles (stderr)
+        HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long c[30];
+        HIP_TRY(hipMemcpy(c, ws.counters, sizeof c, hipMemcpyDeviceToHost));
+        static const char *names[10] = {"box", "sphere", "quad", "other", "exchange", "exchange-none", "idle", "svc-shade", "svc-end", "svc-poll"};
+        unsigned long long total = 0;
+        for (int q = 0; q < 10; ++q) total += c[q * 3];
+        fprintf(stderr, "pool profile (%u slots, %d service waves):\n", pool_slots, tn.pool_service);
+        for (int q = 0; q < 10; ++q)
+            if (c[q * 3 + 1]) fprintf(stderr, "  %-14s cycles %5.1f %%  rounds %10llu  lanes/round %5.1f  cycles/round %8.1f\n", names[q], 100.0 * (double)c[q * 3] / (double)total,
+                    c[q * 3 + 1], (double)c[q * 3 + 2] / (double)c[q * 3 + 1], (double)c[q * 3] / (double)c[q * 3 + 1]);
+    }
     if (pooled && tn.pool_check != 0) { // RT_POOL_CHECK=1 (tests): wait, and turn the pool kernel's give-up flag into an error
         HIP_TRY(hipStreamSynchronize(stream));
         for (int h = 0; h < (pipelined ? 2 : 1); ++h) {
@@ -440,6 +479,7 @@ void rt_scene_options_init(rt_scene_options *o) {
     o->walk = RT_WALK_DEFAULT; o->leaf_max = 0; o->refit = -1; o->use_lds = -1;
     o->th_prim = o->th_other = o->th_shade = o->th_box = o->th_new = -1;
     o->sample_buffer_bytes = 0;
+    o->pool = -1;
 }
 
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) { return rt_scene_create_ex(desc, device, nullptr, out_scene); }

@@ -62,8 +62,10 @@ struct Tuning {
     int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
-    int pool = 1;          // 1: ordered LDS-resident scenes render with the pool kernel (ray compaction across stages; RT_POOL)
+    int pool = 0;          // 1: ordered LDS-resident scenes render with the pool kernel (ray compaction across stages; RT_POOL)
+    int pool_prof = 0;     // ... 1: the instrumented variant; prints a per-section cycle profile to stderr after every render (RT_POOL_PROF)
     int pool_check = 0;    // ... 1: every render waits for its launches and reports a launch that flagged itself (RT_POOL_CHECK; tests)
+    int pool_aux = -1, pool_want_words = 8; // ... small tables in the LDS too: 1 yes, 0 no, -1 only if the pool still gets this many words
     int pool_service = 2;  // ... service waves per workgroup (RT_POOL_SERVICE)
     int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)
     int pool_patience = 2, pool_full = 64; // ... idle polls before a service wave takes a partial word; entries that make a word 'full'

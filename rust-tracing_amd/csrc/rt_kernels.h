@@ -117,7 +117,7 @@ constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quad
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
 int kernel_threads_for(uint32_t kernel_features, int lds); // workgroup size of that instantiation
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux);
-const void *pool_kernel_for(uint32_t feat, bool aux); // ordered, LDS-resident scenes (lds level 3)
+const void *pool_kernel_for(uint32_t feat, bool aux, bool prof); // ordered, LDS-resident scenes (lds level 3)
 size_t pool_ctl_bytes();
 constexpr size_t POOL_SLOT_BYTES = 96;
 

@@ -26,17 +26,28 @@ namespace {
 
 constexpr uint32_t POOL_MAX_WORDS = 16;
 constexpr uint32_t POOL_IDLE_LIMIT = 4000000u; // consecutive fruitless polls (about a second) before a wave gives up and flags the launch
+struct alignas(16) PoolWord {      // the four bitmaps of one word of 64 slots, side by side: one 32-byte read shows a word's state
+    unsigned long long box;   // slot holds a fresh ray: a query to start
+    unsigned long long shade; // slot holds a finished query that hit something: to shade
+    unsigned long long end;   // slot holds a path that has ended (or a query that hit nothing): products, store, next job
+    unsigned long long free_; // slot holds only an id
+};
 struct PoolCtl {
-    unsigned long long box[POOL_MAX_WORDS];   // slot holds a fresh ray: a query to start
-    unsigned long long shade[POOL_MAX_WORDS]; // slot holds a finished query that hit something: to shade
-    unsigned long long end[POOL_MAX_WORDS];   // slot holds a path that has ended (or a query that hit nothing): products, store, next job
-    unsigned long long free_[POOL_MAX_WORDS]; // slot holds only an id
+    PoolWord w[POOL_MAX_WORDS];
     uint32_t live;      // paths in existence in this workgroup (created - ended)
     uint32_t exhausted; // service waves that have no job left to hand out
     uint32_t done;      // every wave leaves
     uint32_t progress;  // service rounds completed (idle waves watch it: no progress anywhere for long = something is wrong)
 };
 static_assert(sizeof(PoolCtl) == 4 * POOL_MAX_WORDS * 8 + 16, "PoolCtl layout");
+RT_DEV PoolWord load_word(const PoolWord *p) { // two 16-byte LDS reads (relaxed: the claims that follow are the atomics that count)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 a = *reinterpret_cast<const volatile u32x4 *>(p), b = *(reinterpret_cast<const volatile u32x4 *>(p) + 1);
+    PoolWord r;
+    r.box = ((uint64_t)a.y << 32) | a.x; r.shade = ((uint64_t)a.w << 32) | a.z;
+    r.end = ((uint64_t)b.y << 32) | b.x; r.free_ = ((uint64_t)b.w << 32) | b.z;
+    return r;
+}
 
 // traversal-lane states beyond the walk's own stages (rt_kernel.hip Stage: 0 box, 1 sphere, 2 quad, 3 other)
 enum PoolStage : uint32_t { PS_BOX = 0, PS_SPHERE = 1, PS_QUAD = 2, PS_OTHER = 3, PS_XSHADE = 4, PS_XEND = 5, PS_EMPTY = 6 };
@@ -76,7 +87,10 @@ RT_DEV uint4 pack_meta(uint32_t job, uint32_t depth, uint32_t n_att, uint32_t be
     return uint4{job, (depth & 0xffffu) | (n_att << 16), best_prim, (id & 0xffffu) | (((uint32_t)(best_inst + 1) & 0xffu) << 16) | (term << 24)};
 }
 
-template <int LDS, int THREADS, uint32_t FEAT, bool AUX>
+// PROF: per section, shader cycles / rounds / lanes served, summed over waves into P.counters (RT_POOL_PROF=1, tools/sweep_pool.sh)
+//   0 box  1 sphere  2 quad  3 other  4 exchange (progress)  5 exchange (nothing to swap with)  6 idle traversal rounds
+//   7 shade service  8 end service  9 service polls
+template <int LDS, int THREADS, uint32_t FEAT, bool AUX, bool PROF = false>
 __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
     static_assert(LDS == 3, "the pool kernel walks LDS-resident ordered scenes");
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
@@ -117,14 +131,29 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
     const uint32_t n_service = P.pool_service_waves;
     const uint32_t ids_per_block = n_slots + THREADS;
     if (threadIdx.x < POOL_MAX_WORDS) {
-        ctl->box[threadIdx.x] = 0; ctl->shade[threadIdx.x] = 0; ctl->end[threadIdx.x] = 0;
-        ctl->free_[threadIdx.x] = threadIdx.x < n_words ? ~0ull : 0ull;
+        ctl->w[threadIdx.x].box = 0; ctl->w[threadIdx.x].shade = 0; ctl->w[threadIdx.x].end = 0;
+        ctl->w[threadIdx.x].free_ = threadIdx.x < n_words ? ~0ull : 0ull;
     }
     if (threadIdx.x == 0) { ctl->live = 0; ctl->exhausted = 0; ctl->done = 0; ctl->progress = 0; }
     for (uint32_t s = threadIdx.x; s < n_slots; s += THREADS) *pool.field(5, s) = uint4{0u, 0u, PRIM_NONE, s}; // a free slot holds its id
     __syncthreads();
 
     Counts cn{};
+    unsigned long long pf_cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_rounds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_lanes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pf_t = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    auto pf_mark = [&](uint32_t slot, uint32_t lanes) {
+        if constexpr (PROF) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            pf_cyc[slot] += t - pf_t; pf_rounds[slot] += 1; pf_lanes[slot] += lanes;
+            pf_t = t;
+        }
+    };
+    auto pf_flush = [&]() {
+        if constexpr (PROF) {
+            if (lane == 0 && P.counters)
+                for (uint32_t q = 0; q < 10; ++q) { atomicAdd(&P.counters[q * 3], pf_cyc[q]); atomicAdd(&P.counters[q * 3 + 1], pf_rounds[q]); atomicAdd(&P.counters[q * 3 + 2], pf_lanes[q]); }
+        }
+    };
     const uint32_t att_stride = P.n_threads * 3u; // (pool launches: n_threads = workgroups x (slots + threads) path ids)
     double *const att_block = P.att_stack + (size_t)blockIdx.x * ids_per_block * 3u;
     const int32_t w = P.cam.image_width, h = P.cam.image_height;
@@ -140,9 +169,8 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
             // ---- look at the bitmaps: a full word of one kind, else (after a few idle polls) the fullest one ----
             unsigned long long m_shade = 0, m_end = 0, m_free = 0;
             if (lane < n_words) {
-                m_shade = __hip_atomic_load(&ctl->shade[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                m_end = __hip_atomic_load(&ctl->end[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                m_free = __hip_atomic_load(&ctl->free_[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const PoolWord pw = load_word(&ctl->w[lane]);
+                m_shade = pw.shade; m_end = pw.end; m_free = pw.free_;
             }
             const uint32_t c_shade = (uint32_t)__popcll(m_shade), c_end = (uint32_t)__popcll(m_end) + (jobs_left ? (uint32_t)__popcll(m_free) : 0u);
             const uint32_t want = idle_polls >= P.pool_patience ? 1u : P.pool_full;
@@ -180,6 +208,7 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                     break;
                 }
                 __builtin_amdgcn_s_sleep(8);
+                pf_mark(9, 0);
                 continue;
             }
             idle_polls = 0;
@@ -187,7 +216,7 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
             if (!do_end) {
                 // ---------------- shade 64 closest hits: ray_color (src/renderer.rs:139-155), one level of the recursion ----------------
                 uint64_t got = 0;
-                if (lane == 0) got = atomicAnd(&ctl->shade[pick], 0ull);
+                if (lane == 0) got = atomicAnd(&ctl->w[pick].shade, 0ull);
                 got = uniform64(got);
                 if (got == 0) continue;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (the slots' contents were written before their bits were set)
@@ -330,16 +359,17 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                 const uint64_t m_to_end = __ballot(mine && to_end), m_to_box = got & ~m_to_end;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the slot writes are in the LDS before the bitmaps say so
                 if (lane == 0) {
-                    if (m_to_box) atomicOr(&ctl->box[pick], m_to_box);
-                    if (m_to_end) atomicOr(&ctl->end[pick], m_to_end);
+                    if (m_to_box) atomicOr(&ctl->w[pick].box, m_to_box);
+                    if (m_to_end) atomicOr(&ctl->w[pick].end, m_to_end);
                     atomicAdd(&ctl->progress, 1u);
                 }
+                pf_mark(7, (uint32_t)__popcll(got));
             } else {
                 // ---------------- end 64 paths: products of the parked attenuations, sample store, next job, Camera::get_ray ----------------
                 uint64_t got_end = 0, got_free = 0;
                 if (lane == 0) {
-                    got_end = atomicAnd(&ctl->end[pick], 0ull);
-                    if (jobs_left) got_free = atomicAnd(&ctl->free_[pick], 0ull);
+                    got_end = atomicAnd(&ctl->w[pick].end, 0ull);
+                    if (jobs_left) got_free = atomicAnd(&ctl->w[pick].free_, 0ull);
                 }
                 got_end = uniform64(got_end); got_free = uniform64(got_free);
                 if ((got_end | got_free) == 0) continue;
@@ -452,12 +482,14 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                 if (lane == 0) {
                     const int32_t delta = (int32_t)__popcll(m_created) - (int32_t)__popcll(got_end);
                     if (delta != 0) atomicAdd(&ctl->live, (uint32_t)delta);
-                    if (m_created) atomicOr(&ctl->box[pick], m_created);
-                    if (m_freed) atomicOr(&ctl->free_[pick], m_freed);
+                    if (m_created) atomicOr(&ctl->w[pick].box, m_created);
+                    if (m_freed) atomicOr(&ctl->w[pick].free_, m_freed);
                     atomicAdd(&ctl->progress, 1u);
                 }
+                pf_mark(8, (uint32_t)__popcll(got_end | got_free));
             }
         }
+        pf_flush();
         return;
     }
 
@@ -664,7 +696,7 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
         }
     };
 
-    uint32_t idle_rounds = 0, seen_progress = 0, x_backoff = 0;
+    uint32_t idle_rounds = 0, seen_progress = 0, x_backoff = 0, x_rounds = 0;
     for (;;) {
         // ---------------- scheduler ----------------
         const uint32_t c_box = (uint32_t)__popcll(__ballot(stage == PS_BOX));
@@ -714,6 +746,7 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                 }
                 in_box = (uint32_t)__popcll(__ballot(stage == PS_BOX));
             } while (in_box >= P.th_box && in_box > 0);
+            pf_mark(0, c_box);
         } else if (HAS_SPHERES && run == PS_SPHERE) {
             // ---------------- Sphere::hit (src/sphere.rs:58-83), one sphere per round ----------------
             if (stage == PS_SPHERE) {
@@ -748,6 +781,7 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                 prim_cur = q + 1;
                 if (prim_cur >= prim_end) o_next(false, 0u);
             }
+            pf_mark(1, c_sph);
         } else if (HAS_QUADS && run == PS_QUAD) {
             // ---------------- Quad::hit (src/quad.rs:96-127): all quads of the leaf (HittableList order) ----------------
             if (stage == PS_QUAD) {
@@ -773,6 +807,7 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                 prim_cur = prim_end;
                 o_next(false, 0u);
             }
+            pf_mark(2, c_quad);
         } else if (HAS_OTHER && run == PS_OTHER) {
             // ---------------- frame changes and the world sequence's steps ----------------
             if (HAS_MEDIA && stage == PS_OTHER && node == NODE_SEQ_NEXT) {
@@ -802,91 +837,102 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                 if (leaving) o_next(false, 0u);
                 else { node = inst_tab[cur_inst].root; stage = PS_BOX; }
             }
+            pf_mark(3, c_oth);
         } else {
             // ---------------- exchange: finished queries out, fresh rays in ----------------
+            // One look at the bitmaps, ONE claiming instruction (lane 0 claims for the lanes with a hit to shade, lane 1 for those
+            // whose query or path ended — in different words, so that a word fills up with one kind), the slot reads, the slot
+            // writes, one publishing instruction.  Empty lanes (start and end of a launch) are served in rounds of their own.
             bool progress = false;
-            unsigned long long b_box = 0, b_shade = 0, b_end = 0, b_free = 0;
-            if (lane < n_words) {
-                b_box = __hip_atomic_load(&ctl->box[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                b_shade = __hip_atomic_load(&ctl->shade[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                b_end = __hip_atomic_load(&ctl->end[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                b_free = __hip_atomic_load(&ctl->free_[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            PoolWord pw{0, 0, 0, 0};
+            if (lane < n_words) pw = load_word(&ctl->w[lane]);
+            const uint32_t kS = (uint32_t)__popcll(m_xs), kE = (uint32_t)__popcll(m_xe);
+            // (lanes left empty by a push into a free slot must not starve behind the pushers: every other round is theirs)
+            x_rounds++;
+            const bool pushers = (kS | kE) != 0 && !(m_em != 0 && (x_rounds & 1u));
+            // word per group: fresh rays to swap with (else free slots to push into), no entries of the other kind; preferably one
+            // that already collects this kind.  starving (nobody walks): any word with room.
+            auto choose = [&](unsigned long long mine_k, unsigned long long other_k, uint32_t taken) -> uint32_t {
+                const bool usable = lane < n_words && lane != taken;
+                const bool has_box = pw.box != 0, has_room = (pw.box | pw.free_) != 0;
+                uint64_t c1 = __ballot(usable && has_box && other_k == 0 && mine_k != 0);
+                if (!c1) c1 = __ballot(usable && has_box && other_k == 0);
+                if (!c1) c1 = __ballot(usable && has_room && other_k == 0);
+                if (!c1 && walking == 0) c1 = __ballot(usable && has_room);
+                return c1 ? (uint32_t)__builtin_ctzll(c1) : 0xffffffffu;
+            };
+            uint32_t pickS = 0xffffffffu, pickE = 0xffffffffu;
+            if (pushers) {
+                if (kS >= kE) { if (kS) pickS = choose(pw.shade, pw.end, 0xffffffffu); if (kE) pickE = choose(pw.end, pw.shade, pickS); }
+                else { if (kE) pickE = choose(pw.end, pw.shade, 0xffffffffu); if (kS) pickS = choose(pw.shade, pw.end, pickE); }
+            } else if (m_em) {
+                const uint64_t c1 = __ballot(lane < n_words && pw.box != 0);
+                if (c1) pickS = (uint32_t)__builtin_ctzll(c1); // (the empty lanes borrow group S's plumbing)
             }
-            // three groups, one claim each: lanes with a hit to shade, lanes with an ended query, empty lanes
-#pragma unroll 1
-            for (uint32_t group = 0; group < 3; ++group) {
-                const uint64_t xm = group == 0 ? m_xs : (group == 1 ? m_xe : m_em);
-                const uint32_t k = (uint32_t)__popcll(xm);
-                if (k == 0) continue;
-                // a word to swap with: fresh rays (or, for a finished query, at least free slots), and — so that words fill up with
-                // one kind — no entries of the other kind; preferably one that already collects this kind
-                const unsigned long long mine_k = group == 0 ? b_shade : b_end, other_k = group == 0 ? b_end : b_shade;
-                const bool has_box = b_box != 0, has_room = (b_box | (group == 2 ? 0ull : b_free)) != 0;
-                const bool compatible = group == 2 || other_k == 0;
-                uint64_t c1 = __ballot(lane < n_words && has_box && compatible && (group == 2 || mine_k != 0));
-                if (!c1) c1 = __ballot(lane < n_words && has_box && compatible);
-                if (!c1) c1 = __ballot(lane < n_words && has_room && compatible);
-                if (!c1 && walking == 0) c1 = __ballot(lane < n_words && has_room); // starving: any word will do
-                if (!c1) continue;
-                const uint32_t pick = (uint32_t)__builtin_ctzll(c1);
-                const uint64_t w_box = readlane64(b_box, pick), w_free = readlane64(b_free, pick);
-                const bool from_box = w_box != 0; // (fresh rays first: a swap; only without any, a push into free slots)
-                const uint64_t cand = from_box ? w_box : w_free;
-                const uint64_t m = __ballot(((cand >> lane) & 1ull) && mbcnt64(cand) < k);
-                uint64_t got = 0;
-                if (lane == 0) got = atomicAnd(from_box ? &ctl->box[pick] : &ctl->free_[pick], ~m) & m;
-                got = uniform64(got);
-                if (got == 0) continue;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // the i-th exchanging lane takes the i-th claimed slot
-                const bool in_got = (got >> lane) & 1ull;
-                const uint32_t g = (uint32_t)__popcll(got);
-                const uint32_t sent = (uint32_t)__builtin_amdgcn_ds_permute((int)((in_got ? mbcnt64(got) : 63u) << 2), (int)lane);
-                const bool xlane = (xm >> lane) & 1ull;
-                const uint32_t my_rank = mbcnt64(xm);
-                const uint32_t slot_lane = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((my_rank & 63u) << 2), (int)sent);
-                const bool valid = xlane && my_rank < g;
-                // (a claimed slot that no lane takes cannot be: g <= k and ranks 0 .. g-1 all exist)
-                if (valid) {
-                    const uint32_t slot = pick * 64u + slot_lane; // (`sent` is defined at the indices below g, and my_rank < g)
-                    const uint4 meta_in = *pool.field(5, slot);
-                    V3 no = o, nd_ = d;
-                    double ntime = time, unused;
-                    Rng nrng = rng;
-                    if (from_box) {
-                        const uint4 f0 = *pool.field(0, slot), f1 = *pool.field(1, slot), f2 = *pool.field(2, slot), f3 = *pool.field(3, slot), f4 = *pool.field(4, slot);
-                        unpack2(f0, no.x, no.y); unpack2(f1, no.z, nd_.x); unpack2(f2, nd_.y, nd_.z); unpack2(f3, ntime, unused);
-                        nrng.x = ((uint64_t)f4.y << 32) | f4.x; nrng.y = ((uint64_t)f4.w << 32) | f4.z;
-                    }
-                    if (group != 2) { // leave the finished query in the slot
-                        *pool.field(0, slot) = pack2(o.x, o.y);
-                        *pool.field(1, slot) = pack2(o.z, d.x);
-                        *pool.field(2, slot) = pack2(d.y, d.z);
-                        *pool.field(3, slot) = pack2(time, HAS_MEDIA ? best_t : cur_tmax);
-                        *pool.field(4, slot) = uint4{(uint32_t)rng.x, (uint32_t)(rng.x >> 32), (uint32_t)rng.y, (uint32_t)(rng.y >> 32)};
-                        *pool.field(5, slot) = pack_meta(job, depth, n_att, best_prim, my_id, best_inst, PT_BACKGROUND);
-                    } else {          // an empty lane leaves its spare id
-                        *pool.field(5, slot) = uint4{0u, 0u, PRIM_NONE, my_id};
-                    }
-                    my_id = meta_in.w & 0xffffu;
-                    if (from_box) {
-                        o = no; d = nd_; time = ntime; rng = nrng;
-                        job = meta_in.x; depth = meta_in.y & 0xffffu; n_att = meta_in.y >> 16;
-                        start_query();
-                    } else {
-                        stage = PS_EMPTY;
-                    }
+            if ((pickS & pickE) != 0xffffffffu) {
+                const uint64_t xmS = pushers ? m_xs : m_em, xmE = pushers ? m_xe : 0ull;
+                const uint32_t nS = (uint32_t)__popcll(xmS), nE = (uint32_t)__popcll(xmE);
+                const uint32_t wS = pickS != 0xffffffffu ? pickS : 0u, wE = pickE != 0xffffffffu ? pickE : 0u;
+                const uint64_t boxS = readlane64(pw.box, wS), freeS = readlane64(pw.free_, wS), boxE = readlane64(pw.box, wE), freeE = readlane64(pw.free_, wE);
+                const bool fromboxS = boxS != 0 || !pushers, fromboxE = boxE != 0; // fresh rays first: a swap; without any, a push into free slots
+                const uint64_t candS = pickS == 0xffffffffu ? 0ull : (fromboxS ? boxS : freeS), candE = pickE == 0xffffffffu ? 0ull : (fromboxE ? boxE : freeE);
+                const uint64_t mS = __ballot(((candS >> lane) & 1ull) && mbcnt64(candS) < nS), mE = __ballot(((candE >> lane) & 1ull) && mbcnt64(candE) < nE);
+                // the claim: lane 0 for group S, lane 1 for group E, one LDS instruction
+                unsigned long long old = 0;
+                if (lane < 2) {
+                    unsigned long long *addr = lane == 0 ? (fromboxS ? &ctl->w[wS].box : &ctl->w[wS].free_) : (fromboxE ? &ctl->w[wE].box : &ctl->w[wE].free_);
+                    const unsigned long long mask = lane == 0 ? mS : mE;
+                    if (mask) old = atomicAnd(addr, ~mask);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) {
-                    if (group == 0) atomicOr(&ctl->shade[pick], got);
-                    else if (group == 1) atomicOr(&ctl->end[pick], got);
-                    else atomicOr(&ctl->free_[pick], got);
+                const uint64_t gotS = readlane64(old, 0) & mS, gotE = readlane64(old, 1) & mE;
+                if (gotS | gotE) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    // the i-th lane of a group takes the group's i-th claimed slot
+                    const uint32_t gS = (uint32_t)__popcll(gotS), gE = (uint32_t)__popcll(gotE);
+                    const uint32_t sentS = (uint32_t)__builtin_amdgcn_ds_permute((int)((((gotS >> lane) & 1ull) ? mbcnt64(gotS) : 63u) << 2), (int)lane);
+                    const uint32_t sentE = (uint32_t)__builtin_amdgcn_ds_permute((int)((((gotE >> lane) & 1ull) ? mbcnt64(gotE) : 63u) << 2), (int)lane);
+                    const bool inS = (xmS >> lane) & 1ull, inE = (xmE >> lane) & 1ull;
+                    const uint32_t my_rank = inS ? mbcnt64(xmS) : mbcnt64(xmE);
+                    const uint32_t laneS = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((my_rank & 63u) << 2), (int)sentS);
+                    const uint32_t laneE = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((my_rank & 63u) << 2), (int)sentE);
+                    const bool valid = (inS && my_rank < gS) || (inE && my_rank < gE);
+                    if (valid) {
+                        const uint32_t slot = inS ? wS * 64u + laneS : wE * 64u + laneE;
+                        const bool from_box = inS ? fromboxS : fromboxE;
+                        const uint4 meta_in = *pool.field(5, slot);
+                        uint4 f0{}, f1{}, f2{}, f3{}, f4{};
+                        if (from_box) { f0 = *pool.field(0, slot); f1 = *pool.field(1, slot); f2 = *pool.field(2, slot); f3 = *pool.field(3, slot); f4 = *pool.field(4, slot); }
+                        if (pushers) { // leave the finished query in the slot
+                            *pool.field(0, slot) = pack2(o.x, o.y);
+                            *pool.field(1, slot) = pack2(o.z, d.x);
+                            *pool.field(2, slot) = pack2(d.y, d.z);
+                            *pool.field(3, slot) = pack2(time, HAS_MEDIA ? best_t : cur_tmax);
+                            *pool.field(4, slot) = uint4{(uint32_t)rng.x, (uint32_t)(rng.x >> 32), (uint32_t)rng.y, (uint32_t)(rng.y >> 32)};
+                            *pool.field(5, slot) = pack_meta(job, depth, n_att, best_prim, my_id, best_inst, PT_BACKGROUND);
+                        } else {        // an empty lane leaves its spare id
+                            *pool.field(5, slot) = uint4{0u, 0u, PRIM_NONE, my_id};
+                        }
+                        my_id = meta_in.w & 0xffffu;
+                        if (from_box) {
+                            double unused;
+                            unpack2(f0, o.x, o.y); unpack2(f1, o.z, d.x); unpack2(f2, d.y, d.z); unpack2(f3, time, unused);
+                            rng.x = ((uint64_t)f4.y << 32) | f4.x; rng.y = ((uint64_t)f4.w << 32) | f4.z;
+                            job = meta_in.x; depth = meta_in.y & 0xffffu; n_att = meta_in.y >> 16;
+                            start_query();
+                        } else {
+                            stage = PS_EMPTY;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane < 2) { // publish: lane 0 group S's slots, lane 1 group E's (empty lanes: the slots they emptied are free)
+                        const unsigned long long bits = lane == 0 ? gotS : gotE;
+                        unsigned long long *addr = lane == 0 ? (pushers ? &ctl->w[wS].shade : &ctl->w[wS].free_) : &ctl->w[wE].end;
+                        if (bits) atomicOr(addr, bits);
+                    }
+                    progress = true;
                 }
-                // (what this wave just took is gone from its picture of the bitmaps too)
-                if (lane == pick) { if (from_box) b_box &= ~got; else b_free &= ~got; if (group == 0) b_shade |= got; else if (group == 1) b_end |= got; else b_free |= got; }
-                progress = true;
             }
+            pf_mark(progress ? 4u : 5u, c_x);
             if (!progress && walking == 0) {
                 if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
                 const uint32_t now_progress = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl->progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -898,22 +944,27 @@ __global__ __launch_bounds__(THREADS, 1) void pool_kernel(const KParams P) {
                     break;
                 }
                 __builtin_amdgcn_s_sleep(4);
+                pf_mark(6, 0);
             } else {
                 idle_rounds = 0;
                 if (!progress) x_backoff = 6; // (lanes are walking: let them)
             }
         }
     }
+    pf_flush();
 }
 
 } // namespace
 
 namespace rtk {
 
-const void *pool_kernel_for(uint32_t feat, bool aux) {
-    if (feat == FEAT_SPHERES_SOLID) return aux ? (const void *)pool_kernel<3, LDS_THREADS, FEAT_SPHERES_SOLID, true> : (const void *)pool_kernel<3, LDS_THREADS, FEAT_SPHERES_SOLID, false>;
-    if (feat == FEAT_QUADS_FRAMES) return aux ? (const void *)pool_kernel<3, LDS_THREADS, FEAT_QUADS_FRAMES, true> : (const void *)pool_kernel<3, LDS_THREADS, FEAT_QUADS_FRAMES, false>;
-    return aux ? (const void *)pool_kernel<3, LDS_THREADS_GENERAL, F_ALL, true> : (const void *)pool_kernel<3, LDS_THREADS_GENERAL, F_ALL, false>;
+const void *pool_kernel_for(uint32_t feat, bool aux, bool prof) {
+#define RT_POOL_PICK(T, F) (prof ? (aux ? (const void *)pool_kernel<3, T, F, true, true> : (const void *)pool_kernel<3, T, F, false, true>) \
+                                 : (aux ? (const void *)pool_kernel<3, T, F, true, false> : (const void *)pool_kernel<3, T, F, false, false>))
+    if (feat == FEAT_SPHERES_SOLID) return RT_POOL_PICK(LDS_THREADS, FEAT_SPHERES_SOLID);
+    if (feat == FEAT_QUADS_FRAMES) return RT_POOL_PICK(LDS_THREADS, FEAT_QUADS_FRAMES);
+    return RT_POOL_PICK(LDS_THREADS_GENERAL, F_ALL);
+#undef RT_POOL_PICK
 }
 size_t pool_ctl_bytes() { return sizeof(PoolCtl); }
 
