@@ -365,7 +365,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         }
         // th_new == 0: no separate path-end rounds — every shade round ends with the path-end block (for its own lanes that
         // just finished and any that were waiting), and the two queues count as one (measured better on final_scene)
-        const bool merged = HAS_TEXTURES || P.th_new == 0; // (the general kernels are always merged: less code, fewer spills)
+        const bool merged = P.th_new == 0; // (the every-feature presets keep it merged: measured best on final_scene, tools/tune.py)
         const uint32_t n_shade = (uint32_t)__popcll(__ballot(stage == ST_SHADE));
         const uint32_t n_new = (uint32_t)__popcll(__ballot(stage - ST_NEWJOB < 4u));
         const uint32_t c_shade = merged ? n_shade + n_new : n_shade;
