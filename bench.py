@@ -111,7 +111,14 @@ def main():
     hs = rt.HostScene(wl["scene"], scene_seed=SCENE_SEED, width=wl["width"], aspect=wl["aspect"], spp=wl["spp"],
                       depth=wl["depth"], earth_image=wl.get("earth_image"), bvh=args.bvh)
     w, h, spp = hs.width, hs.height, hs.camera.samples_per_pixel
-    scene = rt.DeviceScene(hs, device=local_rank)  # scene resident in HBM before timing
+    # One launch per frame where the frame's per-sample buffer (24 B per sample) fits 16 GiB on this rank — then "one launch" is
+    # "one step", and the render kernel's average duration in a rocprofv3 trace of this command is the frame's kernel time.  A
+    # bigger frame (C4, C5) keeps the library's default (2 GiB, several pipelined launches per frame; `launches_per_step` below).
+    n_local_tiles = (((w + 7) // 8) * ((h + 7) // 8) + world - 1) // world
+    one_launch_bytes = n_local_tiles * 64 * 24 * spp
+    sample_buffer = one_launch_bytes if one_launch_bytes <= (16 << 30) else 0
+    scene = rt.DeviceScene(hs, device=local_rank, sample_buffer_bytes=sample_buffer)  # scene resident in HBM before timing
+    launches_per_step = 1 if sample_buffer else -(-spp // max(1, (1 << 30) // (n_local_tiles * 64 * 24)))
 
     stream = torch.cuda.current_stream()
     frame = torch.zeros(w * h * 3, dtype=torch.float64, device=dev)
@@ -224,7 +231,9 @@ def main():
             "roofline": {
                 "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "path_kernel (render megakernel)", "kernel_ms": round(k_ms, 3),
+                "kernel": "path_kernel (render megakernel) + sum_samples_kernel", "kernel_ms": round(k_ms, 3),
+                "launches_per_step": launches_per_step,
+                "sample_buffer_bytes": sample_buffer or "library default (2 GiB, two pipelined halves)",
                 "algorithmic_flops_per_sample": round(flops_ps, 1), "algorithmic_bytes_per_sample": round(bytes_ps, 1),
                 "events_per_sample": {k: round(v, 3) for k, v in per.items() if k != "samples"},
                 "executed_events_per_sample": {k: round(v, 3) for k, v in executed_per.items() if k != "samples"},
