@@ -985,34 +985,42 @@ __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restric
 namespace rtk {
 
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
-    if (lds == 3 && (scene_features & ~FEAT_SPHERES_SOLID) == 0) return FEAT_SPHERES_SOLID;
-    if (lds == 3 && (scene_features & ~FEAT_QUADS_FRAMES) == 0) return FEAT_QUADS_FRAMES;
     (void)ordered;
+    if (lds == 3) { // the specialised instantiations exist for scenes that live in the LDS whole
+        for (uint32_t f : {FEAT_SPHERES_SOLID, FEAT_QUADS_FRAMES, FEAT_QUADS_FRAMES_MEDIA, FEAT_SPHERES_QUADS_TEXTURES})
+            if ((scene_features & ~f) == 0) return f;
+    }
     return F_ALL;
 }
 int kernel_threads_for(uint32_t kernel_features, int lds) {
     if (lds == 0) return GLOBAL_THREADS;
-    return kernel_features == F_ALL ? LDS_THREADS_GENERAL : LDS_THREADS;
+    return (kernel_features == FEAT_SPHERES_SOLID || kernel_features == FEAT_QUADS_FRAMES) ? LDS_THREADS : LDS_THREADS_GENERAL;
 }
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
 #define RT_PICK(L, T, F, O, A) (counted ? (const void *)path_kernel<true, L, T, F, O, A> : (const void *)path_kernel<false, L, T, F, O, A>)
+#define RT_PICK_AUX(L, T, F) (aux ? RT_PICK(L, T, F, true, true) : RT_PICK(L, T, F, true, false))
     if (ordered) { // (AUX: the small tables in the LDS as well, wherever they fit — rt_api.cpp decides)
         if (lds == 3) {
-            if (feat == FEAT_SPHERES_SOLID) return aux ? RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true, true) : RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, true, false);
-            if (feat == FEAT_QUADS_FRAMES) return aux ? RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true, true) : RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, true, false);
-            return aux ? RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, true, true) : RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, true, false);
+            if (feat == FEAT_SPHERES_SOLID) return RT_PICK_AUX(3, LDS_THREADS, FEAT_SPHERES_SOLID);
+            if (feat == FEAT_QUADS_FRAMES) return RT_PICK_AUX(3, LDS_THREADS, FEAT_QUADS_FRAMES);
+            if (feat == FEAT_QUADS_FRAMES_MEDIA) return RT_PICK_AUX(3, LDS_THREADS_GENERAL, FEAT_QUADS_FRAMES_MEDIA);
+            if (feat == FEAT_SPHERES_QUADS_TEXTURES) return RT_PICK_AUX(3, LDS_THREADS_GENERAL, FEAT_SPHERES_QUADS_TEXTURES);
+            return RT_PICK_AUX(3, LDS_THREADS_GENERAL, F_ALL);
         }
-        if (lds == 1) return aux ? RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, true, true) : RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, true, false);
-        return aux ? RT_PICK(0, GLOBAL_THREADS, F_ALL, true, true) : RT_PICK(0, GLOBAL_THREADS, F_ALL, true, false);
+        if (lds == 1) return RT_PICK_AUX(1, LDS_THREADS_GENERAL, F_ALL);
+        return RT_PICK_AUX(0, GLOBAL_THREADS, F_ALL);
     }
     if (lds == 3) {
         if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false, false);
         if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, false, false);
+        if (feat == FEAT_QUADS_FRAMES_MEDIA) return RT_PICK(3, LDS_THREADS_GENERAL, FEAT_QUADS_FRAMES_MEDIA, false, false);
+        if (feat == FEAT_SPHERES_QUADS_TEXTURES) return RT_PICK(3, LDS_THREADS_GENERAL, FEAT_SPHERES_QUADS_TEXTURES, false, false);
         return RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, false, false);
     }
     if (lds == 2) return RT_PICK(2, LDS_THREADS_GENERAL, F_ALL, false, false);
     if (lds == 1) return RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, false, false);
     return RT_PICK(0, GLOBAL_THREADS, F_ALL, false, false);
+#undef RT_PICK_AUX
 #undef RT_PICK
 }
 

@@ -114,6 +114,9 @@ constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 // ones for scenes that fit the LDS entirely and use a subset of the features (BASELINE configs 1/2 and 3).
 constexpr uint32_t FEAT_SPHERES_SOLID = F_SPHERES;          // random-spheres: spheres, solid colours
 constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quads, cubes in Translate/RotateY frames
+// two more, at 768 threads (3 waves per SIMD), which need no spill there: 156 and 150 registers (the every-feature kernel: 168 + 16..38 spilled)
+constexpr uint32_t FEAT_QUADS_FRAMES_MEDIA = F_QUADS | F_FRAMES | F_MEDIA;              // cornell_smoke
+constexpr uint32_t FEAT_SPHERES_QUADS_TEXTURES = F_SPHERES | F_QUADS | F_TEXTURES;    // two_spheres, earth, two_perlin_spheres, simple_light
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
 int kernel_threads_for(uint32_t kernel_features, int lds); // workgroup size of that instantiation
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux);
