@@ -14,7 +14,7 @@
 namespace rt {
 
 enum class BvhPolicy { Reference, Sah };
-BvhPolicy &bvh_policy(); // process-wide; default Reference
+BvhPolicy &bvh_policy(); // the calling thread's; default Reference
 
 class BVHNode : public Hittable {
   public:

@@ -40,6 +40,11 @@ int rth_scene_build(const rth_scene_options *options, rth_scene **out_scene) {
         so.max_depth = options->max_depth;
         so.earth_image = options->earth_image ? options->earth_image : "synthetic:1024x512";
 
+        // (the policy is this thread's and is put back afterwards: the caller's later builds see what they saw before)
+        struct PolicyScope {
+            BvhPolicy saved = bvh_policy();
+            ~PolicyScope() { bvh_policy() = saved; }
+        } policy_scope;
         bvh_policy() = options->bvh_policy == 1 ? BvhPolicy::Sah : BvhPolicy::Reference;
         seed_rng(options->scene_seed);
 

@@ -6,8 +6,8 @@ HostRng &thread_rng() {
     thread_local HostRng rng(1);
     return rng;
 }
-BvhPolicy &bvh_policy() {
-    static BvhPolicy p = BvhPolicy::Reference;
+BvhPolicy &bvh_policy() { // per thread, like thread_rng(): concurrent scene builds do not see each other's choice
+    thread_local BvhPolicy p = BvhPolicy::Reference;
     return p;
 }
 

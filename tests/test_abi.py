@@ -64,6 +64,24 @@ def test_no_gpu_means_an_error_not_a_fallback(rt):
     assert b"no CPU path" in lib.rt_last_error()
 
 
+def test_scene_options_are_checked_before_anything_else(rt):
+    """rt_scene_options: defaults from rt_scene_options_init; an unknown struct size or walk is an argument error (no GPU
+    needed to find out); a shorter struct of an older caller is accepted."""
+    lib = rt.amd_lib()
+    o = rt.scene_options()
+    assert (o.struct_size, o.walk, o.refit, o.use_lds, o.th_prim, o.sample_buffer_bytes, o.pool) == (C.sizeof(rt.SceneCreateOptions), -1, -1, -1, -1, 0, -1)
+    hs = rt.HostScene(4, width=16, spp=1)
+    handle = C.c_void_p()
+    for bad in (dict(struct_size=4), dict(struct_size=4096), dict(walk=7)):
+        opts = rt.scene_options(**bad)
+        assert lib.rt_scene_create_ex(C.byref(hs.desc), 0, C.byref(opts), C.byref(handle)) == -1, bad  # RT_ERR_INVALID_ARGUMENT
+    older = rt.scene_options(struct_size=48, walk=rt.RT_WALK_REFERENCE_ORDER)  # (the struct as it was before `pool` was added)
+    rc = lib.rt_scene_create_ex(C.byref(hs.desc), 0, C.byref(older), C.byref(handle))
+    assert rc == (0 if lib.rt_device_count() > 0 else -2)
+    if rc == 0:
+        lib.rt_scene_destroy(handle)
+
+
 def test_ctypes_structs_match_the_c_layout(rt, tmp_path):
     structs = {"rt_vec3": rt.Vec3, "rt_aabb": rt.Aabb, "rt_ref": rt.Ref, "rt_sphere": rt.Sphere, "rt_quad": rt.Quad,
                "rt_list": rt.List, "rt_translate": rt.Translate, "rt_rotate_y": rt.RotateY, "rt_bvh_node": rt.BvhNode,
