@@ -994,7 +994,8 @@ uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
 }
 int kernel_threads_for(uint32_t kernel_features, int lds) {
     if (lds == 0) return GLOBAL_THREADS;
-    return (kernel_features == FEAT_SPHERES_SOLID || kernel_features == FEAT_QUADS_FRAMES) ? LDS_THREADS : LDS_THREADS_GENERAL;
+    if (kernel_features == FEAT_QUADS_FRAMES) return QUADS_FRAMES_THREADS;
+    return kernel_features == FEAT_SPHERES_SOLID ? LDS_THREADS : LDS_THREADS_GENERAL;
 }
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
 #define RT_PICK(L, T, F, O, A) (counted ? (const void *)path_kernel<true, L, T, F, O, A> : (const void *)path_kernel<false, L, T, F, O, A>)
@@ -1002,7 +1003,7 @@ const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, 
     if (ordered) { // (AUX: the small tables in the LDS as well, wherever they fit — rt_api.cpp decides)
         if (lds == 3) {
             if (feat == FEAT_SPHERES_SOLID) return RT_PICK_AUX(3, LDS_THREADS, FEAT_SPHERES_SOLID);
-            if (feat == FEAT_QUADS_FRAMES) return RT_PICK_AUX(3, LDS_THREADS, FEAT_QUADS_FRAMES);
+            if (feat == FEAT_QUADS_FRAMES) return RT_PICK_AUX(3, QUADS_FRAMES_THREADS, FEAT_QUADS_FRAMES);
             if (feat == FEAT_QUADS_FRAMES_MEDIA) return RT_PICK_AUX(3, LDS_THREADS_GENERAL, FEAT_QUADS_FRAMES_MEDIA);
             if (feat == FEAT_SPHERES_QUADS_TEXTURES) return RT_PICK_AUX(3, LDS_THREADS_GENERAL, FEAT_SPHERES_QUADS_TEXTURES);
             return RT_PICK_AUX(3, LDS_THREADS_GENERAL, F_ALL);
@@ -1012,7 +1013,7 @@ const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, 
     }
     if (lds == 3) {
         if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false, false);
-        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, LDS_THREADS, FEAT_QUADS_FRAMES, false, false);
+        if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, QUADS_FRAMES_THREADS, FEAT_QUADS_FRAMES, false, false);
         if (feat == FEAT_QUADS_FRAMES_MEDIA) return RT_PICK(3, LDS_THREADS_GENERAL, FEAT_QUADS_FRAMES_MEDIA, false, false);
         if (feat == FEAT_SPHERES_QUADS_TEXTURES) return RT_PICK(3, LDS_THREADS_GENERAL, FEAT_SPHERES_QUADS_TEXTURES, false, false);
         return RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, false, false);

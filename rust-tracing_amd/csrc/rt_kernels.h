@@ -108,6 +108,10 @@ constexpr int LDS_THREADS = RT_LDS_THREADS;     // scene in LDS: one 16-wave wor
 #define RT_LDS_THREADS_GENERAL 768 // the every-feature kernels: 12 waves = 3 per SIMD, 170 registers each (at 128 they spill 80-140 of them)
 #endif
 constexpr int LDS_THREADS_GENERAL = RT_LDS_THREADS_GENERAL;
+#ifndef RT_QUADS_FRAMES_THREADS
+#define RT_QUADS_FRAMES_THREADS RT_LDS_THREADS // the quads + frames kernel (Cornell): 128 registers with 6-10 spilled at 1024 threads; tools A/B: 768
+#endif
+constexpr int QUADS_FRAMES_THREADS = RT_QUADS_FRAMES_THREADS;
 constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 
 // The kernel instantiations that exist: the general one (every feature) at each LDS level, plus specialised

@@ -962,7 +962,7 @@ const void *pool_kernel_for(uint32_t feat, bool aux, bool prof) {
 #define RT_POOL_PICK(T, F) (prof ? (aux ? (const void *)pool_kernel<3, T, F, true, true> : (const void *)pool_kernel<3, T, F, false, true>) \
                                  : (aux ? (const void *)pool_kernel<3, T, F, true, false> : (const void *)pool_kernel<3, T, F, false, false>))
     if (feat == FEAT_SPHERES_SOLID) return RT_POOL_PICK(LDS_THREADS, FEAT_SPHERES_SOLID);
-    if (feat == FEAT_QUADS_FRAMES) return RT_POOL_PICK(LDS_THREADS, FEAT_QUADS_FRAMES);
+    if (feat == FEAT_QUADS_FRAMES) return RT_POOL_PICK(QUADS_FRAMES_THREADS, FEAT_QUADS_FRAMES);
     return RT_POOL_PICK(LDS_THREADS_GENERAL, F_ALL); // (also for the two 768-thread specialisations: a superset of their features)
 #undef RT_POOL_PICK
 }
