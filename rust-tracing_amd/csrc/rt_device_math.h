@@ -1,5 +1,5 @@
 // Device-side f64 arithmetic for the render kernel: Vec3 in the reference's operation order, the ABI's
-// counter-based RNG and the five fixed transcendental algorithms (include/rt_amd.h, "Normative definitions").
+// seeded per-path RNG (a stream keyed by a hash of the (seed, pixel, sample) counters) and the fixed transcendental algorithms (include/rt_amd.h, "Normative definitions").
 // Compiled with -ffp-contract=off: a*b+c is two roundings, exactly as the Rust reference computes it.
 #pragma once
 #include <hip/hip_runtime.h>

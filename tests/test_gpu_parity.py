@@ -56,7 +56,7 @@ def test_device_arithmetic_matches_oracle(rt, oracle, gpu):
     p = rng.uniform(0, 1, n)
     assert_bit_equal(rt.debug_eval(rt.RT_DEBUG_POW5, p), vec(L.orc_pow5, p), "pow5")
 
-    # the counter-based generator
+    # the per-path generator (stream `key`, draw number n)
     keys = rng.integers(0, 1 << 63, 2000, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
     draws = rng.integers(0, 100, 2000, dtype=np.uint64)
     kf = keys.view(np.float64); df = draws.view(np.float64)

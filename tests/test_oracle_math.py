@@ -1,5 +1,5 @@
 """The oracle's fixed transcendental algorithms (include/rt_amd.h "Arithmetic") against the platform libm, and the
-counter-based generator's basic properties.  (The GPU's copies are compared with these bit for bit in
+per-path generator's basic properties.  (The GPU's copies are compared with these bit for bit in
 tests/test_gpu_parity.py.)"""
 import math
 
