@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2 /* 2: per-path RomuDuoJr streams (the normative RNG changed: frames differ from abi 1), scene options, gather */
 
 typedef enum rt_status {
     RT_OK = 0,

@@ -20,7 +20,7 @@ from pathlib import Path
 _PKG_DIR = Path(__file__).resolve().parent
 LIB_DIR = _PKG_DIR / "lib"
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_TILE_W = 8
 RT_TILE_H = 8
 RT_OUT_FRAME = 0

@@ -440,7 +440,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
 extern "C" {
 
 const char *rt_last_error(void) { return g_last_error.c_str(); }
-const char *rt_version(void) { return "rt_amd 0.1 (gfx950, abi 1)"; }
+const char *rt_version(void) { return "rt_amd 0.2 (gfx950, abi 2)"; }
 
 int rt_device_count(void) {
     int n = 0;
