@@ -51,3 +51,21 @@ def test_pool_kernel_shards_and_sample_ranges(rt, gpu):
         tiles = ds.render(rt.render_params(seed=2, shard_index=r, shard_count=3))
         frame += tiles  # (RT_OUT_FRAME: each shard writes its own pixels, zeros elsewhere)
     assert (bits(frame) == bits(whole)).all()
+
+
+def test_pool_kernel_full_frames_equal_path_kernel(rt, gpu):
+    """BASELINE configs[1] and [2] at their full image sizes (24 / 64 of their spp): 23 M and 23 M paths through the pool —
+    every workgroup's pool fills and drains thousands of times — give path_kernel's frame, value for value."""
+    import hashlib
+    import torch
+
+    def frame(hs, pool):
+        ds = rt.DeviceScene(hs, pool=pool)
+        out = torch.zeros(hs.width * hs.height * 3, dtype=torch.float64, device="cuda")
+        ds.render_device(rt.render_params(seed=1), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()
+
+    for scene, width, aspect, spp in ((0, 1200, 1.5, 24), (6, 600, 1.0, 64)):
+        hs = rt.HostScene(scene, scene_seed=1, width=width, aspect=aspect, spp=spp, depth=50)
+        assert frame(hs, 1) == frame(hs, 0)
