@@ -216,3 +216,44 @@ def test_furnace(rt, oracle):
     # 0.7 and 0.8 are not dyadic: the in-order sum of k copies differs from k * x by rounding only
     assert np.allclose(out, k[:, None] * bg[None, :], rtol=1e-15, atol=0)
     assert k.mean() > 3.5
+
+
+def test_single_object_furnaces(rt, oracle):
+    """One convex object under a white sky (1, 1, 1): what each material returns is known in closed form from the reference's
+    scatter functions — a convex Lambertian or mirror sphere is left after exactly one bounce (src/material.rs:26-64: the
+    scattered ray points away from the surface), so every sample that hits it IS its albedo; glass attenuates by Color::ONE
+    (src/material.rs:99), so it returns the sky unless the depth runs out; a light returns its emission, whatever the sky
+    (src/renderer.rs:148-150); a white Isotropic medium (src/material.rs:132-138) changes nothing."""
+    import custom_scenes
+    cam = rt.HostScene(4, width=48, spp=6, depth=50)  # the `quads` camera: looks down -z from (0, 0, 9)
+    spp = 6
+
+    def frame(build):
+        s = custom_scenes.CustomScene(cam, spp=spp, depth=50, background=(1.0, 1.0, 1.0))
+        return oracle.render(s.finish(build(s)), rt.render_params(seed=9)).reshape(-1, 3)
+
+    def summed(x):  # the in-order sum of spp copies of x (src/renderer.rs:35-40)
+        acc = 0.0
+        for _ in range(spp):
+            acc += x
+        return acc
+
+    sky = summed(1.0)
+
+    def check_flat(out, colour):
+        """Pixels whose samples all hit the object are exactly `colour`; silhouette pixels (some samples miss) lie between it and the sky."""
+        hit = out[:, 0] != sky
+        assert 0.05 < hit.mean() < 0.9
+        for c in range(3):
+            full = out[hit, c] == summed(colour[c])
+            assert full.mean() > 0.6  # (the rest are silhouette pixels)
+            lo, hi = sorted((summed(colour[c]), sky))
+            assert np.all((out[hit, c] >= lo - 1e-12) & (out[hit, c] <= hi + 1e-12))
+
+    check_flat(frame(lambda s: s.sphere((0, 0, 0), 3.0, s.lambertian(0.8, 0.3, 0.55))), (0.8, 0.3, 0.55))
+    check_flat(frame(lambda s: s.sphere((0, 0, 0), 3.0, s.metal(0.9, 0.6, 0.2, 0.0))), (0.9, 0.6, 0.2))
+    out = frame(lambda s: s.sphere((0, 0, 0), 3.0, s.dielectric(1.5)))
+    assert out.max() == sky and (out == sky).mean() > 0.999 and out.min() >= summed(1.0) - 1.0  # (a path may run out of depth inside)
+    check_flat(frame(lambda s: s.quad((-2, -2, 0), (4, 0, 0), (0, 4, 0), s.light(4.0, 2.0, 0.5))), (4.0, 2.0, 0.5))
+    out = frame(lambda s: s.list([s.medium(s.sphere((0, 0, 0), 3.0, s.dielectric(1.5)), 0.8, 1.0, 1.0, 1.0)]))
+    assert np.all(out == sky)
