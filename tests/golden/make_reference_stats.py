@@ -12,8 +12,14 @@ background (no dependence on the sky), at the committed settings:
 Different tables move the marble's veins, not its average: the image mean is reproduced to a fraction of a per cent
 whatever the tables, and the means over a 3x3 grid to a few per cent — which pins Sphere::hit, the sphere and quad lights, the
 noise texture and the 16:9 camera, none of which the Cornell scenes contain.
+A fourth shows final_scene, whose build-time randomness is confined to parts of the frame: the 400 box heights of the ground (the lower
+third), the 1000 small spheres of the white cube and the Perlin tables of the marble sphere.  Everything else in it — the quad light, the fog
+filling the room, the motion-blurred sphere, the earth (assets/earth-large.jpg, which the repo holds), the fuzzy metal sphere — is fixed by the
+committed code, and those blocks of the frame must come out the same whatever the scene seed:
+    final_scene.png    800x800    src/main.rs:508-639
+It is the only screenshot that exercises Metal, Dielectric, the moving sphere, both ConstantMediums, Translate/RotateY and ImageTexture.
 (earth.png, perlin.png and random_balls.png were rendered by an older revision with a gradient sky, like checker.png
-below; final_scene.png depends on the reference's earth-small.jpg and on 400 random box heights: none of them is used.)
+below: none of them is used.)
 (checker.png shows the deterministic two_spheres scene too, but it was rendered by an older revision with a
 gradient sky: its sky pixels are (229,240,255), whereas the committed constant background (0.7,0.8,1.0),
 src/main.rs:163, encodes to (217,231,255).  Geometry agrees, colours cannot, so it is not used as a pin.)
@@ -39,6 +45,7 @@ SHOTS = {
     "cornell_box": {"file": "screenshots/cornell_box.png", "scene": 6, "source": "src/main.rs:344-421"},
     "cornell_smoke": {"file": "screenshots/cornell_smoke.png", "scene": 7, "source": "src/main.rs:423-506"},
     "simple_light": {"file": "screenshots/simple_light.png", "scene": 5, "source": "src/main.rs:296-342"},
+    "final_scene": {"file": "screenshots/final_scene.png", "scene": 8, "source": "src/main.rs:508-639"},
 }
 
 
