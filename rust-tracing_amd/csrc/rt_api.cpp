@@ -23,7 +23,7 @@ int fail(int status, const std::string &msg) {
 Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_OVERLAP", overlap);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_OVERLAP", overlap);
     env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
@@ -342,9 +342,11 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? tn.quads_frames : (scene->ordered ? tn.ordered_general : tn.general)));
+        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? (scene->insts.bytes ? tn.quads_frames : tn.quads_only) : (scene->ordered ? tn.ordered_general : tn.general)));
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
     }
+    // (a lane keeps the instances it has yet to walk as one 32-bit mask of their indices)
+    K.defer_instances = (scene->ordered && tn.defer != 0 && scene->insts.bytes / sizeof(Instance) <= 32u) ? 1u : 0u;
     if (pooled) { // (the pool kernel's thresholds are lane counts)
         K.pool_off = pool_off; K.pool_slots = pool_slots; K.pool_service_waves = (uint32_t)tn.pool_service;
         K.pool_patience = (uint32_t)tn.pool_patience; K.pool_full = (uint32_t)tn.pool_full;

@@ -55,7 +55,8 @@ struct Tuning {
     Thresholds general{8, 8, 48, 8, 0};
     Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
     Thresholds spheres_solid{8, 16, 24, 16, 32}; // random-spheres
-    Thresholds quads_frames{8, 16, 40, 4, 8};  // Cornell box (1455 vs 1140 Msamples/s with the spheres preset)
+    Thresholds quads_frames{16, 24, 48, 2, 0}; // Cornell box (tools/tune.py with deferred instances: the merged path end wins, 1838 vs 1700 Msamples/s for round 1's 8/16/40/4/8)
+    Thresholds quads_only{8, 16, 40, 4, 8};    // ... the same kernel on a scene without instances (quads: 13.4 vs 12.8 Gsamples/s with the preset above)
     int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
     int refit = 1;   // 0: walk the reference's own (looser) boxes
@@ -70,6 +71,7 @@ struct Tuning {
     int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)
     int pool_patience = 2, pool_full = 64; // ... idle polls before a service wave takes a partial word; entries that make a word 'full'
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
+    int defer = 1;         // ordered walk: the world frame's instances (<= 32) are walked after the world's own tree, one frame change each instead of two (RT_DEFER)
     int grab_taper = 8;    // guided hand-out: a grab takes at most 1 / (waves x this) of the jobs left (RT_GRAB_TAPER; 0: off; tools/sweep_grabs.sh)
     OrderedOptions ordered_options;
     size_t sample_buffer_bytes = (size_t)2 << 30; // per-(scene, stream) sample buffer at most (halved on out-of-memory)
