@@ -23,7 +23,7 @@ int fail(int status, const std::string &msg) {
 Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_OVERLAP", overlap);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_OVERLAP", overlap);
     env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
@@ -334,6 +334,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.lds_world_off = pool_world_off;
     K.box_extent = scene->box_extent;
+    K.o_start_prim = tn.start_shortcut ? scene->o_start_prim : 0xffffffffu; K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
     K.aux_image = scene->aux_image.ptr; K.aux_bytes = scene->aux_bytes; K.lds_aux_off = (uint32_t)aux_offset(scene, lds);
@@ -342,7 +343,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? tn.spheres_solid : (kf == FEAT_QUADS_FRAMES ? (scene->insts.bytes ? tn.quads_frames : tn.quads_only) : (scene->ordered ? tn.ordered_general : tn.general)));
+        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? (scene->ordered ? tn.spheres_solid : tn.spheres_threaded) : (kf == FEAT_QUADS_FRAMES ? (scene->insts.bytes ? tn.quads_frames : tn.quads_only) : (scene->ordered ? tn.ordered_general : tn.general)));
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
     }
     // (a lane keeps the instances it has yet to walk as one 32-bit mask of their indices)
@@ -532,6 +533,24 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
     s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
     s->n_oseq = (uint32_t)cs.oseq.size();
+    // Start shortcut: random-spheres' ground sphere (r = 1000) spans the scene, so the sweep puts it directly under the root and every
+    // ray's origin lies inside its box — the walk visits the root, finds that leaf "nearest", tests the sphere, comes back for the other
+    // child.  When the root has such a child (a single sphere whose box has at least half the area of the root's), a query starts in the
+    // sphere stage with the other child already set aside: the same tests in the same order, minus the visit of the root record.
+    if (cs.ordered && cs.media.empty() && cs.oseq.size() == 1 && cs.oseq[0].kind == OSEQ_TREE) {
+        const ONode &root = cs.onodes[s->o_root];
+        auto half_area = [](const float *b) { const double x = (double)b[1] - b[0], y = (double)b[3] - b[2], z = (double)b[5] - b[4]; return x * y + y * z + z * x; };
+        float all[6];
+        for (int k = 0; k < 6; k += 2) { all[k] = std::fmin(root.b0[k], root.b1[k]); all[k + 1] = std::fmax(root.b0[k + 1], root.b1[k + 1]); }
+        for (uint32_t slot = 0; slot < 2; ++slot) {
+            const uint32_t ref = root.c[slot], other = root.c[slot ^ 1u];
+            const bool single_sphere = (ref >> OREF_KIND_SHIFT) == OK_SPHERES && ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) == 0;
+            if (single_sphere && (other >> OREF_KIND_SHIFT) != OK_EMPTY && half_area(slot ? root.b1 : root.b0) >= 0.5 * half_area(all)) {
+                s->o_start_prim = ref & OREF_INDEX_MASK; s->o_start_rest = other; s->o_start_slot = slot;
+                break;
+            }
+        }
+    }
     for (const ONode &nd : cs.onodes)
         for (int k = 0; k < 6; ++k) {
             if ((nd.c[0] >> OREF_KIND_SHIFT) != OK_EMPTY) s->box_extent = std::fmax(s->box_extent, std::fabs(nd.b0[k]));

@@ -54,8 +54,9 @@ struct Thresholds { uint32_t prim, other, shade, box, newjob; };
 struct Tuning {
     Thresholds general{8, 8, 48, 8, 0};
     Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
-    Thresholds spheres_solid{8, 16, 24, 16, 32}; // random-spheres
+    Thresholds spheres_solid{6, 16, 32, 6, 28};  // random-spheres (re-tuned with the start shortcut: 5070 vs 4900 Msamples/s at 50 spp for round 1's 8/16/24/16/32)
     Thresholds quads_frames{16, 24, 48, 2, 0}; // Cornell box (tools/tune.py with deferred instances: the merged path end wins, 1838 vs 1700 Msamples/s for round 1's 8/16/40/4/8)
+    Thresholds spheres_threaded{8, 16, 24, 16, 32}; // ... the same kernel walking the reference's order (no shortcut there)
     Thresholds quads_only{8, 16, 40, 4, 8};    // ... the same kernel on a scene without instances (quads: 13.4 vs 12.8 Gsamples/s with the preset above)
     int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
     int use_lds = 1; // 0: always gather the scene from global memory (tuning / A-B runs)
@@ -71,6 +72,7 @@ struct Tuning {
     int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)
     int pool_patience = 2, pool_full = 64; // ... idle polls before a service wave takes a partial word; entries that make a word 'full'
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
+    int start_shortcut = 1; // a root whose one child is a single sphere spanning the scene (random-spheres' ground): queries start with that sphere's test (RT_START_SHORTCUT)
     int defer = 1;         // ordered walk: the world frame's instances (<= 32) are walked after the world's own tree, one frame change each instead of two (RT_DEFER)
     int grab_taper = 8;    // guided hand-out: a grab takes at most 1 / (waves x this) of the jobs left (RT_GRAB_TAPER; 0: off; tools/sweep_grabs.sh)
     OrderedOptions ordered_options;
@@ -130,6 +132,7 @@ struct rt_scene {
     rtapi::DeviceArray<uint4> aux_image;                // materials | textures | frames | media | Perlin for the AUX kernels (0 bytes: not used)
     uint32_t aux_bytes = 0, aux_off[5] = {0, 0, 0, 0, 0};
     uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
+    uint32_t o_start_prim = 0xffffffffu, o_start_rest = 0, o_start_slot = 0; // KParams::o_start_*
     rt_scene_stats stats{};
     std::mutex mu;
     std::map<hipStream_t, rtapi::Workspace> workspaces; // one per stream: launches on a stream are ordered

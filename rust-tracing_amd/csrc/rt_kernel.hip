@@ -885,6 +885,16 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             node = first_node;
             sp = 0;
             stage = ST_BOX;
+            if constexpr (ORDERED && HAS_SPHERES && !HAS_MEDIA) {
+                if (P.o_start_prim != 0xffffffffu) { // the root's big sphere first, its other child set aside (rt_api.cpp "start shortcut")
+                    const uint32_t rest = P.o_start_rest;
+                    stack[0] = (StackT)(rest < (1u << OREF_KIND_SHIFT) ? rest : (first_node | (P.o_start_slot ? SKIP_CHILD1 : SKIP_CHILD0)));
+                    sp = 1;
+                    prim_cur = P.o_start_prim;
+                    prim_end = prim_cur + 1u;
+                    stage = ST_SPHERE;
+                }
+            }
             if constexpr (ORDERED && HAS_MEDIA) { // the world's sequence starts over
                 seq_pc = 1; // (its first step is a tree: first_node)
                 if (first_node == NODE_SEQ_NEXT) { // ... or a medium: taken here, while the lanes starting a query are together
