@@ -23,7 +23,7 @@ int fail(int status, const std::string &msg) {
 Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_OVERLAP", overlap);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_OVERLAP", overlap);
     env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
@@ -334,6 +334,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
     K.lds_world_off = pool_world_off;
     K.box_extent = scene->box_extent;
+    K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
     K.o_start_prim = tn.start_shortcut ? scene->o_start_prim : 0xffffffffu; K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);

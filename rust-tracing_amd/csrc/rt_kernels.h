@@ -74,6 +74,7 @@ struct KParams {
     // a query may start with a primitive test instead of the root record (rt_api.cpp start_shortcut): the sphere to test (0xffffffff: none),
     // the root's other child, and which child of the root the sphere is
     uint32_t o_start_prim, o_start_rest, o_start_slot;
+    uint32_t seq_lookahead;         // 1: a query that cannot reach any later step of the world's sequence ends it at its start (path_kernel)
     uint32_t lds_stack_off;
     uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)
     uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
