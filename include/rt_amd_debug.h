@@ -46,10 +46,18 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
 /* Test / tuning hook: how scenes created from now on are walked.  ordered = 2: the library's own trees, nearest child
  * first — with media, a sequence of trees and media in the reference's scan order (DESIGN.md "Ordered layout"; a medium
  * inside a Translate / RotateY frame keeps the other walk); 0: every scene walks the reference's tree in the reference's
- * order; 1 (default): as 2, except for scenes measured faster the other way (a handful of primitives; small scenes with
- * box-bounded media).  leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
+ * order; 1 (default): as 2, except for scenes measured faster the other way (a single primitive).
+ * leaf_max > 0: primitives per leaf of those trees at most; 0: back to the default.  Negative: keep.
  * Affects speed only, never results. */
 int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
+
+/* Test / tuning hook: which shortcuts the ordered walk of scenes created / rendered from now on takes (negative: keep).
+ * flat_max: a frame of at most this many primitives keeps them in one leaf under its root (0: off; default 8) — scene creation;
+ * start_shortcut: a query starts with the primitives of a leaf under the root that spans the scene (0 / 1) — per render;
+ * defer_instances: the world frame's instances are walked after its own tree (0 / 1) — per render;
+ * seq_lookahead: a query looks ahead at the later steps of the world's sequence when it starts (0 / 1) — per render.
+ * Affects speed only, never results. */
+int rt_debug_set_walk_shortcuts(int32_t flat_max, int32_t start_shortcut, int32_t defer_instances, int32_t seq_lookahead);
 
 /* Test hook: the ordered layout the scene compiler builds for `desc` (no device needed).  Set the cap_* fields and
  * the pointers (any may be null: only the counts are returned then).

@@ -27,6 +27,7 @@ Tuning::Tuning() {
     env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
+    if (const char *e = getenv("RT_FLAT_MAX")) ordered_options.flat_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
     if (const char *e = getenv("RT_SAH_QUAD")) ordered_options.cost_quad = atof(e);
     if (const char *e = getenv("RT_SAH_INSTANCE")) ordered_options.cost_instance = atof(e);
@@ -335,7 +336,8 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_world_off = pool_world_off;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
-    K.o_start_prim = tn.start_shortcut ? scene->o_start_prim : 0xffffffffu; K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;
+    K.o_start_stage = tn.start_shortcut ? scene->o_start_stage : 0u; K.o_start_prim = scene->o_start_prim; K.o_start_end = scene->o_start_end;
+    K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
     K.lds_seq_off = (uint32_t)seq_offset(scene, lds);
     K.aux_image = scene->aux_image.ptr; K.aux_bytes = scene->aux_bytes; K.lds_aux_off = (uint32_t)aux_offset(scene, lds);
@@ -461,19 +463,12 @@ int64_t rt_out_size(int32_t width, int32_t height, int32_t out_layout, int32_t s
     return -1;
 }
 
-// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py, round 2: small tables and parked
-// world rays in the LDS, 768-thread every-feature kernels), own trees vs reference order, Msamples/s: two_spheres 6713 / 6381,
-// earth 20107 / 20514 (one primitive: a tree and a stack are pure overhead), two_perlin_spheres 4079 / 3234, simple_light
-// 5392 / 4744, cornell_smoke 947 / 977 (18 quads, and two media whose rotated-box boundaries are walked as trees of their own,
-// twice per visit); round 1: quads 15790 / 14393, cornell_box 2206 / 1967, random_balls 3557 / 2038, final_scene 821 / 624.
+// Which walk for this scene?  Measured on MI355X at the in-code cameras (tools/scene_speed.py, profiles/r02_scene_speed.txt), own trees
+// vs reference order, Msamples/s: random_balls 4416 / 2128, two_spheres 8739 / 7281, earth 22557 / 22523 (one primitive: a tree and a
+// stack are pure overhead), two_perlin_spheres 4821 / 3288, quads 12860 / 12612, simple_light 5845 / 4894, cornell_box 3224 / 2102,
+// cornell_smoke 1261 / 966 (a tie until its frames' primitives went into flat leaves, rt_ordered.hpp flat_max), final_scene 983 / 643.
 static bool ordered_walk_pays(const CompiledScene &cs) {
-    const size_t prims = cs.spheres.size() + cs.quads.size();
-    if (prims <= 1) return false;
-    bool general_boundary = false;
-    for (const Node &n : cs.nodes)
-        if ((n.kind & NODE_KIND_MASK) == NK_MEDIUM_ENTER) general_boundary = true;
-    if (general_boundary && prims < 64) return false;
-    return true;
+    return cs.spheres.size() + cs.quads.size() > 1;
 }
 
 void rt_scene_options_init(rt_scene_options *o) {
@@ -534,20 +529,27 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
     s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
     s->n_oseq = (uint32_t)cs.oseq.size();
-    // Start shortcut: random-spheres' ground sphere (r = 1000) spans the scene, so the sweep puts it directly under the root and every
+    // Start shortcut.  random-spheres' ground sphere (r = 1000) spans the scene, so the sweep puts it directly under the root and every
     // ray's origin lies inside its box — the walk visits the root, finds that leaf "nearest", tests the sphere, comes back for the other
-    // child.  When the root has such a child (a single sphere whose box has at least half the area of the root's), a query starts in the
-    // sphere stage with the other child already set aside: the same tests in the same order, minus the visit of the root record.
+    // child; a frame of a few primitives keeps them in one leaf under its root (rt_ordered.hpp flat_max: Cornell's walls).  When the root
+    // has such a child (a leaf whose box has at least half the area of the root's), a query starts in the leaf's primitive stage with the
+    // other child already set aside: the same tests, minus the visit of the root record, and the lanes that start together stay together.
     if (cs.ordered && cs.media.empty() && cs.oseq.size() == 1 && cs.oseq[0].kind == OSEQ_TREE) {
         const ONode &root = cs.onodes[s->o_root];
         auto half_area = [](const float *b) { const double x = (double)b[1] - b[0], y = (double)b[3] - b[2], z = (double)b[5] - b[4]; return x * y + y * z + z * x; };
+        const bool empty0 = (root.c[0] >> OREF_KIND_SHIFT) == OK_EMPTY, empty1 = (root.c[1] >> OREF_KIND_SHIFT) == OK_EMPTY;
         float all[6];
-        for (int k = 0; k < 6; k += 2) { all[k] = std::fmin(root.b0[k], root.b1[k]); all[k + 1] = std::fmax(root.b0[k + 1], root.b1[k + 1]); }
+        for (int k = 0; k < 6; k += 2) {
+            all[k] = empty1 ? root.b0[k] : (empty0 ? root.b1[k] : std::fmin(root.b0[k], root.b1[k]));
+            all[k + 1] = empty1 ? root.b0[k + 1] : (empty0 ? root.b1[k + 1] : std::fmax(root.b0[k + 1], root.b1[k + 1]));
+        }
         for (uint32_t slot = 0; slot < 2; ++slot) {
-            const uint32_t ref = root.c[slot], other = root.c[slot ^ 1u];
-            const bool single_sphere = (ref >> OREF_KIND_SHIFT) == OK_SPHERES && ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) == 0;
-            if (single_sphere && (other >> OREF_KIND_SHIFT) != OK_EMPTY && half_area(slot ? root.b1 : root.b0) >= 0.5 * half_area(all)) {
-                s->o_start_prim = ref & OREF_INDEX_MASK; s->o_start_rest = other; s->o_start_slot = slot;
+            const uint32_t ref = root.c[slot], other = root.c[slot ^ 1u], kind = ref >> OREF_KIND_SHIFT;
+            if ((kind == OK_SPHERES || kind == OK_QUADS) && half_area(slot ? root.b1 : root.b0) >= 0.5 * half_area(all)) {
+                s->o_start_stage = kind; // (OrderedKind SPHERES / QUADS = Stage ST_SPHERE / ST_QUAD)
+                s->o_start_prim = ref & OREF_INDEX_MASK;
+                s->o_start_end = s->o_start_prim + ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u;
+                s->o_start_rest = other; s->o_start_slot = slot;
                 break;
             }
         }

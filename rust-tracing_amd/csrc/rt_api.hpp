@@ -55,7 +55,7 @@ struct Tuning {
     Thresholds general{8, 8, 48, 8, 0};
     Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
     Thresholds spheres_solid{6, 16, 32, 6, 28};  // random-spheres (re-tuned with the start shortcut: 5070 vs 4900 Msamples/s at 50 spp for round 1's 8/16/24/16/32)
-    Thresholds quads_frames{16, 24, 48, 2, 0}; // Cornell box (tools/tune.py with deferred instances: the merged path end wins, 1838 vs 1700 Msamples/s for round 1's 8/16/40/4/8)
+    Thresholds quads_frames{24, 16, 48, 2, 0}; // Cornell box (tools/tune.py; with instances walked last and flat leaves the merged path end wins: round 1's 8/16/40/4/8 is 7 % behind)
     Thresholds spheres_threaded{8, 16, 24, 16, 32}; // ... the same kernel walking the reference's order (no shortcut there)
     Thresholds quads_only{8, 16, 40, 4, 8};    // ... the same kernel on a scene without instances (quads: 13.4 vs 12.8 Gsamples/s with the preset above)
     int forced[5] = {-1, -1, -1, -1, -1};    // prim, other, shade, box, newjob
@@ -133,7 +133,7 @@ struct rt_scene {
     rtapi::DeviceArray<uint4> aux_image;                // materials | textures | frames | media | Perlin for the AUX kernels (0 bytes: not used)
     uint32_t aux_bytes = 0, aux_off[5] = {0, 0, 0, 0, 0};
     uint32_t o_root = 0, o_stack = 0;            // world root record; stack entries per lane
-    uint32_t o_start_prim = 0xffffffffu, o_start_rest = 0, o_start_slot = 0; // KParams::o_start_*
+    uint32_t o_start_stage = 0, o_start_prim = 0, o_start_end = 0, o_start_rest = 0, o_start_slot = 0; // KParams::o_start_*
     rt_scene_stats stats{};
     std::mutex mu;
     std::map<hipStream_t, rtapi::Workspace> workspaces; // one per stream: launches on a stream are ordered

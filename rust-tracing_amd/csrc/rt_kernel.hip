@@ -889,17 +889,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             node = first_node;
             sp = 0;
             stage = ST_BOX;
-            if constexpr (ORDERED && HAS_SPHERES && !HAS_MEDIA) {
+            if constexpr (ORDERED && !HAS_MEDIA) {
                 // (Measured against visiting the root record right here, with its box tests: 5340 vs 5060 Msamples/s on C2.  The blind
-                // test keeps the lanes that start a query together — ONE sphere round serves them all, then they all walk —, and a
-                // round costs the same for 23 lanes as for 43: the 1.2 tests per sample spent on rays that miss the sphere's box are free.)
-                if (P.o_start_prim != 0xffffffffu) { // the root's big sphere first, its other child set aside (rt_api.cpp "start shortcut")
+                // test keeps the lanes that start a query together — ONE round of the primitive stage serves them all, then they all walk
+                // —, and a round costs the same for 23 lanes as for 43: the 1.2 tests per sample spent on rays that miss the leaf's box are free.)
+                if (P.o_start_stage != 0u) { // the root's big leaf first, its other child set aside (rt_api.cpp "start shortcut")
                     const uint32_t rest = P.o_start_rest;
-                    stack[0] = (StackT)(rest < (1u << OREF_KIND_SHIFT) ? rest : (first_node | (P.o_start_slot ? SKIP_CHILD1 : SKIP_CHILD0)));
-                    sp = 1;
+                    if ((rest >> OREF_KIND_SHIFT) != OK_EMPTY) {
+                        stack[0] = (StackT)(rest < (1u << OREF_KIND_SHIFT) ? rest : (first_node | (P.o_start_slot ? SKIP_CHILD1 : SKIP_CHILD0)));
+                        sp = 1;
+                    }
                     prim_cur = P.o_start_prim;
-                    prim_end = prim_cur + 1u;
-                    stage = ST_SPHERE;
+                    prim_end = P.o_start_end;
+                    stage = P.o_start_stage;
                 }
             }
             if constexpr (ORDERED && HAS_MEDIA) { // the world's sequence starts over

@@ -71,9 +71,9 @@ struct KParams {
     uint32_t aux_bytes, lds_aux_off, aux_off_mats, aux_off_texs, aux_off_insts, aux_off_media, aux_off_perlins;
     uint32_t n_oseq;
     uint32_t o_root;
-    // a query may start with a primitive test instead of the root record (rt_api.cpp start_shortcut): the sphere to test (0xffffffff: none),
-    // the root's other child, and which child of the root the sphere is
-    uint32_t o_start_prim, o_start_rest, o_start_slot;
+    // a query may start with the primitives of a leaf under the root instead of the root record (rt_api.cpp "start shortcut"): the stage of the
+    // leaf's kind (ST_SPHERE / ST_QUAD; 0: no shortcut), its primitives [prim, end), the root's other child, which child of the root the leaf is
+    uint32_t o_start_stage, o_start_prim, o_start_end, o_start_rest, o_start_slot;
     uint32_t seq_lookahead;         // 1: a query that cannot reach any later step of the world's sequence ends it at its start (path_kernel)
     uint32_t lds_stack_off;
     uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)

@@ -29,6 +29,8 @@ struct OrderedOptions {
     double cost_quad = 0.8;       // one Quad::hit (most end at the plane test),
     double cost_instance = 6.0;   // and one frame change plus the walk inside
     uint32_t world_depth = 24;    // inner records on a root-to-leaf path at most ...
+    uint32_t flat_max = 8;        // a frame with at most this many primitives (all spheres or all quads; <= OREF_MAX_LEAF) keeps them in ONE leaf
+                                  // under its root, beside the tree of its instances: the lanes that enter the frame test them together (0: off)
     uint32_t frame_slack = 4;     // ... and at most this many more than an even split of the tree's items needs
                                   // (the kernel's stack holds ORDERED_MAX_STACK entries in all, frames below included)
 };
@@ -262,6 +264,30 @@ class OrderedBuilder {
             return;
         }
         if (levels_for(items.size()) > budget) { need_[f] = ORDERED_MAX_STACK + 1; return; }
+        // A frame of a few primitives (Cornell's six walls, the six faces of its boxes): a tree over them culls next to nothing — most rays
+        // visit most of its records, each on its own schedule — whereas the lanes that enter the frame together (a shade or frame-change
+        // round has just served them) can test ONE leaf of them all in one round of the primitive stage.  The root's other child is the
+        // tree of the frame's instances.
+        {
+            const size_t n_prims = (size_t)std::count_if(items.begin(), items.end(), [](const Item &it) { return it.kind != OK_INSTANCE; });
+            std::stable_partition(items.begin(), items.end(), [](const Item &it) { return it.kind != OK_INSTANCE; });
+            bool same = n_prims >= 2 && n_prims <= std::min<size_t>(opt_.flat_max, OREF_MAX_LEAF);
+            for (size_t i = 1; i < n_prims && same; ++i) same = items[i].kind == items[0].kind;
+            if (same && budget >= 1u + (items.size() > n_prims ? levels_for(items.size() - n_prims) : 0u)) {
+                const uint32_t id = alloc_node();
+                const Built l = make_leaf(items, 0, n_prims);
+                set_child(nodes_[id], 0, l);
+                uint32_t need = 1;
+                if (items.size() > n_prims) {
+                    const Built r = build(items, n_prims, items.size(), budget - 1);
+                    set_child(nodes_[id], 1, r);
+                    need = 1u + r.need;
+                }
+                root_[f] = id;
+                need_[f] = need;
+                return;
+            }
+        }
         Built r = build(items, 0, items.size(), budget);
         if ((r.ref >> OREF_KIND_SHIFT) != OK_INNER) { // a frame's root is always a record
             const uint32_t id = alloc_node();

@@ -215,7 +215,9 @@ def test_counters_match_the_oracle_in_tight_mode(rt, oracle, gpu):
                 if ds.stats()["ordered"]:
                     # one visit = one record (two box tests): fewer records than the reference walk tests boxes
                     assert 0 < got["node_visits"] <= 0.6 * want["node_visits"], (name, got["node_visits"], want["node_visits"])
-                    assert got["sphere_tests"] + got["quad_tests"] <= 1.5 * (want["sphere_tests"] + want["quad_tests"])
+                    # (primitive tests may exceed the reference walk's: a frame of a few primitives tests them all, and a query may
+                    # start with the leaf under the root without testing its box — rounds that the wave runs anyway)
+                    assert got["sphere_tests"] + got["quad_tests"] <= 3.0 * (want["sphere_tests"] + want["quad_tests"])
                     assert got["medium_visits"] <= want["medium_visits"] * 1.03 + 2
                     continue
                 # The kernel walks boxes refitted to the geometry (tighter than the reference's, which the oracle walks)
