@@ -112,6 +112,16 @@ def test_frames_inside_frames(rt, oracle, gpu):
     check(rt, oracle, scene, "nested frames")
 
 
+@pytest.mark.parametrize("n", [3, 20, 28, 29, 50])  # 28 cubes: 32 instances with the nested ones, 29: 33
+def test_many_instances(rt, oracle, gpu, n):
+    """Up to 32 instances of the world frame are noted as bits and walked after the world's own tree; more than 32 are
+    entered where the walk meets them: both against the oracle, in both walks."""
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.many_instances_scene(cam, n)
+    assert rt.DeviceScene(scene).stats()["n_instances"] >= n
+    check(rt, oracle, scene, f"{n} instances")
+
+
 def test_random_object_graphs(rt, oracle, gpu):
     """Fuzz: 40 random scenes (tests/custom_scenes.py::random_scene), each rendered by whichever walks it supports."""
     lib = rt.amd_lib()
