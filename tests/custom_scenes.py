@@ -311,10 +311,11 @@ def many_media_scene(camera_from, n=40, seed=11):
     return s.finish(s.list(items))
 
 
-def many_instances_scene(camera_from, n, seed=3):
+def many_instances_scene(camera_from, n, seed=3, spheres=True):
     """n rotated and shifted cubes (each a Translate(RotateY(list of six quads))) beside each other over a floor, some
     overlapping, two of them nested once more — the walk meets many instances per ray.  n <= 32: the world frame's
-    instances are walked after its own tree (one bit each); n > 32: entered where the walk meets them."""
+    instances are walked after its own tree (one bit each); n > 32: entered where the walk meets them.
+    spheres=False: quads only, so that the quads + frames kernel renders it (the one that defers instances)."""
     import random
     rnd = random.Random(seed)
     s = CustomScene(camera_from, spp=4, depth=6, background=(0.7, 0.8, 1.0))
@@ -326,13 +327,15 @@ def many_instances_scene(camera_from, n, seed=3):
                 s.quad((-h, h, h), (2 * h, 0, 0), (0, 0, -2 * h), m), s.quad((-h, -h, -h), (2 * h, 0, 0), (0, 0, 2 * h), m)]
 
     side = max(1, int(math.ceil(math.sqrt(n))))
-    world = [s.quad((-6, -1.5, -6), (12, 0, 0), (0, 0, 12), mats[1]), s.sphere((0.0, 2.5, 0.0), 0.6, mats[3])]
+    world = [s.quad((-6, -1.5, -6), (12, 0, 0), (0, 0, 12), mats[1]),
+             s.sphere((0.0, 2.5, 0.0), 0.6, mats[3]) if spheres else s.quad((-0.6, 2.5, -0.6), (1.2, 0, 0), (0, 0, 1.2), mats[3])]
     for k in range(n):
         gx, gz = k % side, k // side
         h = rnd.uniform(0.15, 0.45)
         inner = s.list(cube(h, mats[k % 3]))
         if k % 7 == 3:  # one more frame inside
-            inner = s.list([s.translate(s.rotate_y(inner, rnd.uniform(-60, 60)), (0.1, 0.2, 0.0)), s.sphere((0.0, -0.4, 0.0), 0.2, mats[2])])
+            extra = s.sphere((0.0, -0.4, 0.0), 0.2, mats[2]) if spheres else s.quad((-0.2, -0.4, -0.2), (0.4, 0, 0), (0, 0, 0.4), mats[2])
+            inner = s.list([s.translate(s.rotate_y(inner, rnd.uniform(-60, 60)), (0.1, 0.2, 0.0)), extra])
         pos = ((gx - side / 2) * 0.9 + rnd.uniform(-0.3, 0.3), rnd.uniform(-1.0, 0.5), (gz - side / 2) * 0.9 + rnd.uniform(-0.3, 0.3))
         world.append(s.translate(s.rotate_y(inner, rnd.uniform(-90, 90)), pos))
     return s.finish(s.list(world))

@@ -112,14 +112,17 @@ def test_frames_inside_frames(rt, oracle, gpu):
     check(rt, oracle, scene, "nested frames")
 
 
+@pytest.mark.parametrize("spheres", [True, False])
 @pytest.mark.parametrize("n", [3, 20, 28, 29, 50])  # 28 cubes: 32 instances with the nested ones, 29: 33
-def test_many_instances(rt, oracle, gpu, n):
-    """Up to 32 instances of the world frame are noted as bits and walked after the world's own tree; more than 32 are
-    entered where the walk meets them: both against the oracle, in both walks."""
+def test_many_instances(rt, oracle, gpu, n, spheres):
+    """Up to 32 instances of the world frame are noted as bits and walked after the world's own tree (quads + frames kernel:
+    spheres=False); more than 32, or any number on the every-feature kernel, are entered where the walk meets them: all against
+    the oracle, in both walks."""
     cam = scene_cases.build(rt, "quads_64x64_8spp")
-    scene = custom_scenes.many_instances_scene(cam, n)
-    assert rt.DeviceScene(scene).stats()["n_instances"] >= n
-    check(rt, oracle, scene, f"{n} instances")
+    scene = custom_scenes.many_instances_scene(cam, n, spheres=spheres)
+    st = rt.DeviceScene(scene).stats()
+    assert st["n_instances"] >= n and (st["n_spheres"] > 0) == spheres
+    check(rt, oracle, scene, f"{n} instances, spheres={spheres}")
 
 
 def test_random_object_graphs(rt, oracle, gpu):
