@@ -30,6 +30,11 @@ namespace {
 // shade+next ray).  Each scheduler round the wave counts its lanes per stage with ballots and runs ONE stage for
 // all the lanes in it: the rare stages are deferred until enough lanes have queued up for them, so that every
 // instruction stream the wave issues has most of its 64 lanes active.
+// A round costs the same for any number of lanes, so what keeps the lanes of a wave TOGETHER is nearly free and what makes a
+// lane wait is dear: a query starts with the primitives of a leaf that spans the scene (start shortcut: one round of the
+// primitive stage for all the lanes a shade round has just served), small frames keep their primitives in one leaf (flat
+// leaves, rt_ordered.hpp), the world's instances are walked after its own tree (no frame change back in between), a query
+// that cannot reach a later step of the world's sequence ends it at its start.
 // (a lane waiting for the path-end stage holds ST_NEWJOB + Terminal: what its path ended on)
 enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST_SHADE = 4, ST_NEWJOB = 5, ST_DONE = 9 };
 // what a path ended on (ST_NEWJOB multiplies the parked attenuations back onto it): the background, Color::ONE (a light:
