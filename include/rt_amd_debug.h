@@ -55,9 +55,12 @@ int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max);
  * flat_max: a frame of at most this many primitives keeps them in one leaf under its root (0: off; default 8) — scene creation;
  * start_shortcut: a query starts with the primitives of a leaf under the root that spans the scene (0 / 1) — per render;
  * defer_instances: the world frame's instances are walked after its own tree (0 / 1) — per render;
- * seq_lookahead: a query looks ahead at the later steps of the world's sequence when it starts (0 / 1) — per render.
+ * seq_lookahead: a query looks ahead at the later steps of the world's sequence when it starts (0 / 1) — per render;
+ * slow_min, slow_age: hits on a noise texture wait in the shade stage for slow_min of their kind, at most slow_age shade rounds
+ * (slow_min 1: nobody waits; defaults 4, 32) — per render.
  * Affects speed only, never results. */
-int rt_debug_set_walk_shortcuts(int32_t flat_max, int32_t start_shortcut, int32_t defer_instances, int32_t seq_lookahead);
+int rt_debug_set_walk_shortcuts(int32_t flat_max, int32_t start_shortcut, int32_t defer_instances, int32_t seq_lookahead,
+                                int32_t slow_min, int32_t slow_age);
 
 /* Test hook: the ordered layout the scene compiler builds for `desc` (no device needed).  Set the cap_* fields and
  * the pointers (any may be null: only the counts are returned then).

@@ -236,7 +236,7 @@ RT_AMD_DEBUG_SYMBOLS = {
                                           C.POINTER(C.c_int64)]),
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
     "rt_debug_set_traversal": (C.c_int, [C.c_int32, C.c_int32]),
-    "rt_debug_set_walk_shortcuts": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rt_debug_set_walk_shortcuts": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_debug_ordered_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_debug_set_tuning": (C.c_int, [C.c_int32] * 6),
 }

@@ -23,7 +23,7 @@ int fail(int status, const std::string &msg) {
 Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
-    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_OVERLAP", overlap);
+    env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
     env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
@@ -99,6 +99,15 @@ bool texture_needs_uv(const std::vector<rt_texture> &texs, int32_t t, int depth 
     const rt_texture &x = texs[(size_t)t];
     if (x.kind == RT_TEXTURE_IMAGE) return true;
     if (x.kind == RT_TEXTURE_CHECKER) return texture_needs_uv(texs, x.even, depth + 1) || texture_needs_uv(texs, x.odd, depth + 1);
+    return false;
+}
+
+// Perlin turbulence anywhere under texture t (seven noise evaluations per lookup: by far the dearest thing a hit can ask for)
+bool texture_has_noise(const std::vector<rt_texture> &texs, int32_t t, int depth = 0) {
+    if (t < 0 || depth > 16) return false;
+    const rt_texture &x = texs[(size_t)t];
+    if (x.kind == RT_TEXTURE_NOISE) return true;
+    if (x.kind == RT_TEXTURE_CHECKER) return texture_has_noise(texs, x.even, depth + 1) || texture_has_noise(texs, x.odd, depth + 1);
     return false;
 }
 
@@ -336,6 +345,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_world_off = pool_world_off;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
+    K.slow_min = (uint32_t)tn.slow_min; K.slow_age = (uint32_t)tn.slow_age;
     K.o_start_stage = tn.start_shortcut ? scene->o_start_stage : 0u; K.o_start_prim = scene->o_start_prim; K.o_start_end = scene->o_start_end;
     K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;
     K.oimage = scene->oimage.ptr; K.o_root = scene->o_root; K.oseq = scene->oseq.ptr; K.n_oseq = scene->n_oseq; K.lds_stack_off = lds_image_bytes_for(scene, lds);
@@ -632,6 +642,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         d.kind = (uint32_t)m.kind;
         d.texture = m.texture >= 0 ? (uint32_t)m.texture : 0u;
         d.needs_uv = texture_needs_uv(cs.textures, m.texture) ? 1u : 0u;
+        d.slow = (m.kind != RT_MATERIAL_METAL && m.kind != RT_MATERIAL_DIELECTRIC && texture_has_noise(cs.textures, m.texture)) ? 1u : 0u;
         d.albedo[0] = m.albedo.x; d.albedo[1] = m.albedo.y; d.albedo[2] = m.albedo.z;
         if (m.kind != RT_MATERIAL_METAL && m.kind != RT_MATERIAL_DIELECTRIC && m.texture >= 0 &&
             cs.textures[(size_t)m.texture].kind == RT_TEXTURE_SOLID) {

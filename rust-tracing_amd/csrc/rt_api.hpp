@@ -72,6 +72,7 @@ struct Tuning {
     int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)
     int pool_patience = 2, pool_full = 64; // ... idle polls before a service wave takes a partial word; entries that make a word 'full'
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
+    int slow_min = 4, slow_age = 32; // KParams::slow_min / slow_age (RT_SLOW_MIN, RT_SLOW_AGE; slow_min 1: nobody waits)
     int seq_lookahead = 1;  // scenes with media: a query looks ahead at the boxes of the sequence's later steps when it starts (RT_SEQ_LOOKAHEAD)
     int start_shortcut = 1; // a root whose one child is a single sphere spanning the scene (random-spheres' ground): queries start with that sphere's test (RT_START_SHORTCUT)
     int defer = 1;         // ordered walk: the world frame's instances (<= 32) are walked after the world's own tree, one frame change each instead of two (RT_DEFER)

@@ -29,14 +29,17 @@ int rt_debug_set_traversal(int32_t ordered, int32_t leaf_max) {
     return RT_OK;
 }
 
-int rt_debug_set_walk_shortcuts(int32_t flat_max, int32_t start_shortcut, int32_t defer_instances, int32_t seq_lookahead) {
-    const int32_t v[4] = {flat_max, start_shortcut, defer_instances, seq_lookahead};
+int rt_debug_set_walk_shortcuts(int32_t flat_max, int32_t start_shortcut, int32_t defer_instances, int32_t seq_lookahead, int32_t slow_min,
+                                int32_t slow_age) {
+    const int32_t v[6] = {flat_max, start_shortcut, defer_instances, seq_lookahead, slow_min, slow_age};
     tuning_update([](Tuning &t, const void *arg) {
         const int32_t *a = static_cast<const int32_t *>(arg);
         if (a[0] >= 0) t.ordered_options.flat_max = (uint32_t)a[0];
         if (a[1] >= 0) t.start_shortcut = a[1];
         if (a[2] >= 0) t.defer = a[2];
         if (a[3] >= 0) t.seq_lookahead = a[3];
+        if (a[4] >= 1) t.slow_min = a[4];
+        if (a[5] >= 0) t.slow_age = a[5];
     }, v);
     return RT_OK;
 }

@@ -394,6 +394,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     } while (0)
     unsigned long long t_prev = COUNT ? __builtin_amdgcn_s_memtime() : 0;
     uint32_t prev_run = ST_NEWJOB;
+    uint32_t slow_waited = 0; // (wave-uniform) shade rounds in a row that left lanes with a dear texture waiting
 
     for (;;) {
         if (COUNT) {
@@ -674,6 +675,22 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     mat = media_tab[pi].phase_material;
                 }
                 const DMaterial *m = &mats_tab[mat];
+                // A hit on a noise texture is rare (final_scene: 0.065 per sample) and dear (Perlin turbulence: seven noise evaluations,
+                // ~1500 instructions), and one such lane makes the whole wave run that code: nearly half of final_scene's shade rounds
+                // did.  Such lanes wait — nothing of theirs has been touched yet, they stay queued for the stage — until slow_min of them
+                // are here, or slow_age shade rounds have passed, or nothing else is: final_scene +2.3 % (4 lanes / 32 rounds; image
+                // lookups, 0.076 per sample and far cheaper, lose by waiting).
+                bool postpone = false;
+                if constexpr (HAS_TEXTURES) {
+                    const bool slow = m->slow != 0u;
+                    const uint32_t n_slow = (uint32_t)__popcll(__ballot(slow));
+                    if (n_slow != 0u) {
+                        const bool go = n_slow >= P.slow_min || slow_waited >= P.slow_age || n_slow == (uint32_t)__popcll(__ballot(true));
+                        slow_waited = go ? 0u : slow_waited + 1u;
+                        postpone = slow && !go;
+                    }
+                }
+                if (!postpone) {
                 if (HAS_TEXTURES && uv_from_sphere && m->needs_uv) { // get_sphere_uv (src/sphere.rs:48-52), from the outward normal
                     const double PI = 3.14159265358979323846264338327950288;
                     const double theta = rt_acos(-outward_normal.y);
@@ -763,6 +780,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 } else {
                     start_query = true; // of the scattered ray
                 }
+                } // (!postpone)
             }
         }
         if (run == ST_NEWJOB || (run == ST_SHADE && merged)) {

@@ -205,7 +205,7 @@ def test_small_frames_keep_their_primitives_in_one_leaf(rt):
     assert len(rt.debug_ordered_layout(scene_cases.build(rt, "c1_random_balls_400x225_10spp_d10"))["nodes"]) == 484
     lib = rt.amd_lib()
     try:
-        lib.rt_debug_set_walk_shortcuts(0, -1, -1, -1)
+        lib.rt_debug_set_walk_shortcuts(0, -1, -1, -1, -1, -1)
         assert len(rt.debug_ordered_layout(hs)["nodes"]) == 17
     finally:
-        lib.rt_debug_set_walk_shortcuts(8, -1, -1, -1)
+        lib.rt_debug_set_walk_shortcuts(8, -1, -1, -1, -1, -1)
