@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the render hot path on N MI355X (BASELINE.json's metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 from a bare shell: starts its own N ranks, see below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one full frame of the workload: every pixel x every sample traced by the HIP kernel
@@ -9,7 +9,13 @@ A step = one full frame of the workload: every pixel x every sample traced by th
 With N > 1 the frame's 8x8 tiles are dealt round-robin to the ranks (no data-path collective) and ONE gather
 (RCCL) brings the tile buffers to rank 0, which reassembles the frame on its GPU — all inside the timed step.
 The image is the same for every N (tests/test_gpu_parity.py, tests/test_sharding_gloo.py), so total work is
-fixed: strong scaling.
+fixed: strong scaling.  The gather is the library's own (rt_gather_tiles_device: grouped ncclSend / ncclRecv, RCCL loaded
+by librt_amd); `--gather torch` or an RT_ERR_COMM at communicator set-up falls back to torch.distributed.gather, and the
+JSON line says which one ran (`gather`).
+
+Started with --gpus N > 1 and no WORLD_SIZE in the environment, this script launches `torch.distributed.run` with N ranks
+of itself as a CHILD process — decided from the arguments and the environment alone, before anything touches a GPU — and
+exits with the child's code.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,6 +50,7 @@ SCENE_SEED = 1
 RENDER_SEED = 1
 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (256 CU x 64 FMA/clk x 2 x 2.4 GHz); SURVEY.md Appendix B
+HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X HBM3E (MI355X_MICROARCH.md)
 
 
 def algorithmic_work_per_sample(cnt):
@@ -58,6 +65,22 @@ def algorithmic_work_per_sample(cnt):
     return flops, bytes_, per
 
 
+def relaunch_under_torchrun(n_ranks):
+    """--gpus N > 1 from a bare shell: one child process runs torch.distributed.run with N ranks of this script.  Nothing in
+    this process has touched a GPU (no HIP call, no torch.cuda call), and the launcher is a child, not an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,13 +90,18 @@ def main():
     ap.add_argument("--bvh", default="reference", choices=["reference", "sah"])
     ap.add_argument("--spp", type=int, default=0, help="override spp (smoke runs only: the JSON then names the reduced config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", default="torch", choices=["torch", "native"],
-                    help="N > 1: the frame-end gather through torch.distributed (RCCL behind it) or through the C ABI's own "
-                         "rt_gather_tiles_device (RCCL loaded by librt_amd; the unique id travels over torch.distributed)")
+    ap.add_argument("--gather", default="native", choices=["native", "torch"],
+                    help="N > 1: the frame-end gather through the C ABI's own rt_gather_tiles_device (RCCL loaded by librt_amd; "
+                         "the unique id travels over torch.distributed) or through torch.distributed.gather (RCCL behind it); "
+                         "native falls back to torch when the library cannot set its communicator up (RT_ERR_COMM)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 control flow on ONE GPU (all ranks share device 0, the gather goes "
                          "through host memory); not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
 
     import numpy as np
     import torch
@@ -86,8 +114,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rehearsal = args.backend == "gloo"
     if rehearsal:
@@ -130,11 +156,34 @@ def main():
     else:
         params = rt.render_params(seed=RENDER_SEED)
 
+    # The gather of the tile buffers: the library's own exchange unless asked otherwise.  Setting the communicator up can fail
+    # for reasons that have nothing to do with the renderer (no librccl to dlopen, a refused bootstrap): every rank then agrees
+    # (one all-reduce of the outcome) to gather through torch.distributed instead, and the JSON line records it.
     comm = None
-    if world > 1 and args.gather == "native" and not rehearsal:
-        ids = [rt.Comm.unique_id() if rank == 0 else None]
+    gather_used = "none (one rank)" if world == 1 else "torch.distributed.gather"
+    if rehearsal:
+        gather_used = "host-staged torch.distributed.gather over gloo (rehearsal)"
+    elif world > 1 and args.gather == "native":
+        why = ""
+        try:
+            ids = [rt.Comm.unique_id() if rank == 0 else None]
+        except rt.RtError as e:
+            ids, why = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
-        comm = rt.Comm.create(ids[0], rank, world, local_rank)
+        if ids[0] is not None:
+            try:
+                comm = rt.Comm.create(ids[0], rank, world, local_rank)
+            except rt.RtError as e:
+                why = str(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            gather_used = "rt_gather_tiles_device (librt_amd: grouped ncclSend / ncclRecv)"
+        else:
+            if comm is not None:
+                comm.close()
+                comm = None
+            gather_used = "torch.distributed.gather (native set-up failed" + (": " + why if why else " on another rank") + ")"
 
     kernel_ms = []
 
@@ -210,13 +259,15 @@ def main():
         # HBM bytes per launch cannot be counted from inside this process: they come from the rocprofv3 PMC passes of
         # tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction), committed per workload in
         # profiles/hbm_traffic.json together with the tag of the build they were measured on
-        traffic, traffic_source = None, "no PMC pass of this workload is committed under profiles/"
+        traffic, traffic_source, hbm_frac = None, "no PMC pass of this workload is committed under profiles/", None
         tp = ROOT / "profiles" / "hbm_traffic.json"
         if tp.exists() and world == 1 and args.spp == 0:
             try:
                 entry = json.loads(tp.read_text()).get(args.workload)
                 if entry:
                     traffic = entry.get("bytes_per_launch")
+                    if traffic:  # measured bytes of one step / this run's kernel time of one step / 8 TB/s
+                        hbm_frac = round(float(traffic) / (k_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, 5)
                     traffic_source = f"profiles/hbm_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build {entry.get('tag')}"
             except Exception:
                 pass
@@ -228,9 +279,11 @@ def main():
             "config": {"workload": wl_name, "scene_seed": SCENE_SEED, "render_seed": RENDER_SEED, "bvh": args.bvh,
                        "width": w, "height": h, "spp": spp, "max_depth": hs.camera.max_depth,
                        "parallelism": (f"tiles{world}" if world > 1 else "single") + (" [gloo rehearsal on one GPU]" if rehearsal else "")},
+            "gather": gather_used,
             "roofline": {
                 "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic, "hbm_frac": hbm_frac,
+                "traffic_source": traffic_source,
                 "kernel": "path_kernel (render megakernel) + sum_samples_kernel", "kernel_ms": round(k_ms, 3),
                 "launches_per_step": launches_per_step,
                 "sample_buffer_bytes": sample_buffer or "library default (2 GiB, two pipelined halves)",

@@ -30,3 +30,21 @@ def test_rtrace_writes_the_same_png_as_the_library_path(rt, gpu, tmp_path):
     # -l/--live needs a window system: refused, not ignored
     r = subprocess.run([str(exe), "-l"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "live" in r.stderr
+
+
+def test_bench_launches_its_own_ranks_from_a_bare_shell(rt, gpu):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts torch.distributed.run itself (as a child, before
+    anything touches the GPU) — here over gloo, both ranks on the box's one GPU — and prints one line for n_gpus = 2."""
+    import json
+    import os
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "c1", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    assert "gloo" in line["gather"] and line["config"]["workload"].startswith("random-spheres 400x225")
