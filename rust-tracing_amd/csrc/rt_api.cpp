@@ -116,11 +116,12 @@ bool texture_has_noise(const std::vector<rt_texture> &texs, int32_t t, int depth
 namespace rtapi {
 void free_workspace(Workspace &w) {
     for (int h = 0; h < 2; ++h) {
-        (void)hipFree(w.half[h].att_stack); (void)hipFree(w.half[h].samples); (void)hipFree(w.half[h].world_slots); (void)hipFree(w.half[h].job_counter);
+        (void)hipFree(w.half[h].att_stack); (void)hipFree(w.half[h].att_ids); (void)hipFree(w.half[h].samples); (void)hipFree(w.half[h].world_slots); (void)hipFree(w.half[h].job_counter);
         if (w.aux[h]) (void)hipStreamDestroy(w.aux[h]);
         if (w.ev_sum[h]) (void)hipEventDestroy(w.ev_sum[h]);
     }
     if (w.ev_start) (void)hipEventDestroy(w.ev_start);
+    if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     (void)hipFree(w.counters);
     w = Workspace();
 }
@@ -253,28 +254,57 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     // (pool kernel: the attenuation stack has one column per path id: slots + threads of every workgroup)
     const uint32_t n_threads = (uint32_t)(grid * (threads + (int64_t)pool_slots));
 
+    // The scratch of this (scene, stream).  The entry is taken — and marked in use — under the scene's lock; the launches are
+    // enqueued outside it on a copy of the handles.  Only entries nobody holds are ever evicted, after waiting for the event their
+    // last render recorded (a library-owned handle: the caller's stream may be gone by then).
     Workspace ws;
+    struct Release {
+        rt_scene *scene; hipStream_t stream; bool armed = false;
+        ~Release() {
+            if (!armed) return;
+            std::lock_guard<std::mutex> lock(scene->mu);
+            auto it = scene->workspaces.find(stream);
+            if (it != scene->workspaces.end() && it->second.in_use > 0) it->second.in_use--;
+        }
+    } release{scene, stream};
+    const bool colours = scene->parks_colours || pooled; // (the pool kernel parks every attenuation as a colour)
     {
         std::lock_guard<std::mutex> lock(scene->mu);
         if (scene->workspaces.find(stream) == scene->workspaces.end() && scene->workspaces.size() >= MAX_WORKSPACES) {
-            // a new stream and the table is full: release the others' buffers once their work has drained
-            for (auto &kv : scene->workspaces) {
-                (void)hipStreamSynchronize(kv.first); // (a stream that no longer exists: nothing of it is in flight)
-                free_workspace(kv.second);
+            // a new stream and the table is full: the idle entries go, once their last render has drained; entries in use stay
+            // (the table then grows past its nominal size rather than pull scratch from under a render that is being enqueued)
+            for (auto it = scene->workspaces.begin(); it != scene->workspaces.end();) {
+                if (it->second.in_use != 0) { ++it; continue; }
+                if (it->second.ev_done) (void)hipEventSynchronize(it->second.ev_done);
+                free_workspace(it->second);
+                it = scene->workspaces.erase(it);
             }
             (void)hipGetLastError();
-            scene->workspaces.clear();
         }
         Workspace &w = scene->workspaces[stream];
-        const size_t need_att = ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double); // + a light's emitted colour
+        const size_t need_att = colours ? ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double) : sizeof(double); // + a light's emitted colour
         if (need_att / sizeof(double) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the attenuation stack's 32-bit indices");
+        const size_t need_ids = ((size_t)p.max_depth + 1u) * n_threads * sizeof(uint32_t);
+        if (need_ids / sizeof(uint32_t) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the index stack's 32-bit indices");
         const size_t need_world = (size_t)6 * n_threads * sizeof(double);
-        if (pipelined && !w.aux[0]) {
-            for (int h = 0; h < 2; ++h) {
-                HIP_TRY(hipStreamCreateWithFlags(&w.aux[h], hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&w.ev_sum[h], hipEventDisableTiming));
+        if (!w.ev_done) HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+        if (pipelined && !w.aux[0]) { // both streams and all three events, or none of them
+            hipStream_t st[2] = {nullptr, nullptr};
+            hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+            hipError_t e = hipSuccess;
+            for (int h = 0; h < 2 && e == hipSuccess; ++h) e = hipStreamCreateWithFlags(&st[h], hipStreamNonBlocking);
+            for (int h = 0; h < 3 && e == hipSuccess; ++h) e = hipEventCreateWithFlags(&ev[h], hipEventDisableTiming);
+            if (e != hipSuccess) {
+                for (int h = 0; h < 2; ++h) if (st[h]) (void)hipStreamDestroy(st[h]);
+                for (int h = 0; h < 3; ++h) if (ev[h]) (void)hipEventDestroy(ev[h]);
+                return fail(RT_ERR_HIP, std::string("rt_render: internal streams: ") + hipGetErrorString(e));
             }
-            HIP_TRY(hipEventCreateWithFlags(&w.ev_start, hipEventDisableTiming));
+            w.aux[0] = st[0]; w.aux[1] = st[1]; w.ev_sum[0] = ev[0]; w.ev_sum[1] = ev[1]; w.ev_start = ev[2];
+        }
+        // (an earlier out-of-memory back-off on this stream is remembered: the buffer it arrived at is the budget from then on)
+        if (w.sample_budget > 0) {
+            const int64_t c = chunk_for(w.sample_budget);
+            if (c >= 1 && c < chunk) chunk = c;
         }
         // (every earlier launch on this stream ends with the stream waiting for the internal ones: draining it drains them)
         bool drained = false;
@@ -287,6 +317,13 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
                 x.att_stack = nullptr; x.att_bytes = 0;
                 HIP_TRY(hipMalloc((void **)&x.att_stack, need_att));
                 x.att_bytes = need_att;
+            }
+            if (x.att_ids_bytes < need_ids) {
+                if ((rc = drain()) != RT_OK) return rc;
+                if (x.att_ids) HIP_TRY(hipFree(x.att_ids));
+                x.att_ids = nullptr; x.att_ids_bytes = 0;
+                HIP_TRY(hipMalloc((void **)&x.att_ids, need_ids));
+                x.att_ids_bytes = need_ids;
             }
             if (x.world_bytes < need_world) {
                 if ((rc = drain()) != RT_OK) return rc;
@@ -310,12 +347,15 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
                         return fail(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("rt_render: sample buffer: ") + hipGetErrorString(e));
                     chunk = (chunk + 1) / 2;
                     need_samples = (size_t)bytes_per_sample_row * (size_t)chunk;
+                    w.sample_budget = need_samples;
                 }
                 x.sample_bytes = need_samples;
             }
             if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, 2 * sizeof(uint32_t))); // [1]: the pool kernel's give-up flag
         }
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
+        w.in_use++;
+        release.armed = true;
         ws = w;
     }
     if (counted || (pooled && tn.pool_prof != 0)) {
@@ -334,6 +374,8 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.seed_mixed = host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
     K.n_nodes = scene->n_nodes;
     K.n_threads = n_threads;
+    K.id_one = (uint32_t)(scene->mats.bytes / sizeof(DMaterial)) - 1u;
+    K.ids_ok = K.id_one < 0xffffu ? 1u : 0u;
     K.max_depth = p.max_depth;
     K.shard_index = p.shard_index; K.shard_count = p.shard_count; K.out_layout = p.out_layout;
     K.tiles_x = (camera->image_width + RT_TILE_W - 1) / RT_TILE_W;
@@ -381,7 +423,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         const int h = pipelined ? (int)(k & 1) : 0;
         const hipStream_t s = pipelined ? ws.aux[h] : stream;
         const LaunchScratch &x = ws.half[h];
-        K.samples = x.samples; K.att_stack = x.att_stack; K.job_counter = x.job_counter; K.world_slots = x.world_slots;
+        K.samples = x.samples; K.att_stack = x.att_stack; K.att_ids = x.att_ids; K.job_counter = x.job_counter; K.world_slots = x.world_slots;
         K.sample_begin = (int32_t)sb;
         K.n_samples = (uint32_t)ns;
         K.n_jobs = (uint32_t)(n_local * 64 * ns);
@@ -414,6 +456,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         if (pipelined) HIP_TRY(hipEventRecord(ws.ev_sum[h], s));
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
+    HIP_TRY(hipEventRecord(ws.ev_done, stream));
     if (pooled && tn.pool_prof != 0) { // RT_POOL_PROF=1: where the pool kernel's waves spent their cycles (stderr)
         HIP_TRY(hipStreamSynchronize(stream));
         unsigned long long c[30];
@@ -535,6 +578,10 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
                   (cs.media.empty() ? 0u : F_MEDIA);
     for (const auto &t : cs.textures)
         if (t.kind != RT_TEXTURE_SOLID) s->features |= F_TEXTURES;
+    // attenuations are parked as material indices unless the colour is a texture's value, or the indices do not fit 16 bits: such a
+    // scene is rendered by the kernels that can park colours, i.e. those with textures
+    if (cs.materials.size() >= 0xffffu) s->features |= F_TEXTURES;
+    s->parks_colours = (s->features & F_TEXTURES) != 0;
     s->ordered = cs.ordered;
     // a walk starts in the first step's tree; a sequence that starts with a medium goes through ST_OTHER first
     s->o_root = cs.ordered && cs.oseq[0].kind == OSEQ_TREE ? cs.oseq[0].a : 0xfffffffeu;
@@ -635,8 +682,11 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
             for (int l = s->lds_level + 1; l < 4; ++l) s->lds_prefix_bytes[l] = 0;
         }
     }
-    std::vector<DMaterial> mats(cs.materials.size());
-    for (size_t i = 0; i < mats.size(); ++i) {
+    // (one entry more than the scene has materials: Color::ONE, what the path end multiplies by for a level a path does not have)
+    std::vector<DMaterial> mats(cs.materials.size() + 1u);
+    mats.back().albedo[0] = mats.back().albedo[1] = mats.back().albedo[2] = 1.0;
+    mats.back().solid = 1u;
+    for (size_t i = 0; i + 1u < mats.size(); ++i) {
         const rt_material &m = cs.materials[i];
         DMaterial d{};
         d.kind = (uint32_t)m.kind;

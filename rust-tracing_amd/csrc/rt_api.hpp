@@ -30,8 +30,10 @@ int fail(int status, const std::string &msg); // sets rt_last_error() of the cal
 // two such sets on two internal streams, so that the next launch's workgroups move in as the current one's drain (its tail)
 // instead of waiting behind its per-pixel summation.
 struct LaunchScratch {
-    double *att_stack = nullptr;
+    double *att_stack = nullptr;   // parked colours (KParams::att_stack): full size only for scenes that park colours
     size_t att_bytes = 0;
+    uint32_t *att_ids = nullptr;   // parked material indices beyond the eight a lane keeps in registers (KParams::att_ids)
+    size_t att_ids_bytes = 0;
     double *world_slots = nullptr; // [6][n_threads]
     size_t world_bytes = 0;
     double *samples = nullptr; // sample buffer of one launch
@@ -40,8 +42,12 @@ struct LaunchScratch {
 };
 struct Workspace {
     LaunchScratch half[2];
-    hipStream_t aux[2] = {nullptr, nullptr};      // created on first use
+    hipStream_t aux[2] = {nullptr, nullptr};      // created on first use (all of them or none)
     hipEvent_t ev_start = nullptr, ev_sum[2] = {nullptr, nullptr};
+    hipEvent_t ev_done = nullptr;                 // recorded on the caller's stream behind every render's last enqueue: what an
+                                                  // eviction waits for (the caller's stream handle itself is never touched again)
+    int in_use = 0;                               // renders that hold a copy of this entry and have not finished enqueueing
+    size_t sample_budget = 0;                     // > 0: the sample buffer size an out-of-memory back-off arrived at
     unsigned long long *counters = nullptr;
 };
 void free_workspace(Workspace &w);
@@ -111,6 +117,7 @@ struct rt_scene {
     rtapi::DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
     uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
     bool has_instances = false;
+    bool parks_colours = false;                 // some attenuation is a texture's value: launches need the colour stack (KParams::att_stack)
     int lds_level = 0;                          // 0 nothing fits, 1 nodes, 2 nodes + spheres, 3 nodes + spheres + quads
     uint32_t features = F_ALL;                  // Feature bits the scene uses
     uint32_t lds_prefix_bytes[4] = {0, 0, 0, 0}; // image prefix each LDS level copies in

@@ -205,16 +205,46 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         return my_seq > best_seq ? i_am_quad : !best_is_quad;
     };
 
-    double *att = P.att_stack + (size_t)gtid * 3u;
-    const uint32_t att_stride = P.n_threads * 3u; // (32-bit element indices: launch_render checks the stack has < 2^32 doubles)
-    // A path that has ended waits for the path-end round; its ray registers are dead by then.  The loads of the last two
-    // attenuations it parked are issued at once into them (o: the last one parked, d: the one before), so that the round that
-    // multiplies them back does not start with a trip to memory (measured: a tenth of the frame's cycles on C2 and C4).
-    const bool background_lit = P.cam.background.x != 0.0 || P.cam.background.y != 0.0 || P.cam.background.z != 0.0;
-    auto prefetch_parked = [&]() {
-        if (!background_lit) return; // (a path that ends on a black background is zero whatever it parked)
-        if (n_att > 0) { const double *slot = att + (n_att - 1u) * att_stride; o = v3(slot[0], slot[1], slot[2]); }
-        if (n_att > 1) { const double *slot = att + (n_att - 2u) * att_stride; d = v3(slot[0], slot[1], slot[2]); }
+    // Parked attenuations.  ray_color multiplies the attenuations back innermost first (src/renderer.rs:147-149), so a path parks one
+    // per bounce and the path end multiplies them onto the terminal, last parked first.  For every material whose attenuation is a
+    // constant — a SolidColor albedo, Metal — what is parked is the material's INDEX (16 bits): the path end reads the colour from the
+    // material table (in the LDS wherever the small tables fit), the same values in the same order.  The last four indices live in two
+    // registers used as a shift register (newest in the low half of ids[0]), so the path end finds them at fixed places; an index that
+    // falls out of them goes to att_ids [level][thread] — 4 bytes per lane, consecutive lanes consecutive addresses.  A texture's value
+    // (Checker / Image / Noise) is parked as the colour itself, in att_stack [level][component][thread], and ID_COLOUR in the index
+    // stack says so (kernels with textures only; a scene with more than 65534 materials is rendered by those).  A level that a path does
+    // not have reads the table's last entry, whose colour is Color::ONE: multiplying by it is the identity, bit for bit.
+    // (Before: three 8-byte stores per bounce at a 24-byte lane stride and as many loads at the path end — 1.8x the bytes in partial
+    // lines, 57 GB of the Cornell frame's 121 GB of writes.)
+    constexpr uint32_t ID_COLOUR = 0xffffu;
+    constexpr uint32_t IDW = 2u, IDS_IN_REGS = 2u * IDW;
+    uint32_t ids[IDW] = {};
+    // (element indices are 32 bits wide — launch_render checks the stacks have < 2^32 elements — and are formed from gtid where they
+    // are used: a scalar base and one offset register instead of a pointer pair kept alive through the whole walk)
+    uint32_t *const att_ids = P.att_ids;
+    double *const att_col = P.att_stack;
+    const uint32_t att_lanes = P.n_threads;
+    auto park = [&](uint32_t id, V3 colour) {
+        if constexpr (HAS_TEXTURES) {
+            if (id == ID_COLOUR) {
+                const uint32_t at = n_att * 3u * att_lanes + gtid;
+                att_col[at] = colour.x; att_col[at + att_lanes] = colour.y; att_col[at + 2u * att_lanes] = colour.z;
+            }
+        }
+        if (n_att >= IDS_IN_REGS) att_ids[(n_att - IDS_IN_REGS) * att_lanes + gtid] = ids[IDW - 1u] >> 16; // the oldest index in the registers makes room
+    #pragma unroll
+        for (uint32_t q = IDW - 1u; q > 0u; --q) ids[q] = __builtin_amdgcn_alignbit(ids[q], ids[q - 1u], 16);
+        ids[0] = (ids[0] << 16) | id;
+        n_att++;
+    };
+    auto parked_colour = [&](uint32_t id, uint32_t level) -> V3 {
+        if constexpr (HAS_TEXTURES) {
+            if (id == ID_COLOUR) {
+                const uint32_t at = level * 3u * att_lanes + gtid;
+                return v3(att_col[at], att_col[at + att_lanes], att_col[at + 2u * att_lanes]);
+            }
+        }
+        return ld3(mats_tab[id].albedo);
     };
 
     // wave-uniform: the job range this wave currently owns
@@ -419,10 +449,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         const uint32_t c_quad = HAS_QUADS ? (uint32_t)__popcll(__ballot(stage == ST_QUAD)) : 0u;
         const uint32_t c_oth = HAS_OTHER ? (uint32_t)__popcll(__ballot(stage == ST_OTHER)) : 0u;
         // a finished query that hit nothing needs no shading: the path ends on the background
-        if (stage == ST_SHADE && best_prim == PRIM_NONE) {
-            stage = ST_NEWJOB + TERM_BACKGROUND;
-            prefetch_parked();
-        }
+        if (stage == ST_SHADE && best_prim == PRIM_NONE) stage = ST_NEWJOB + TERM_BACKGROUND;
         // th_new == 0: no separate path-end rounds — every shade round ends with the path-end block (for its own lanes that
         // just finished and any that were waiting), and the two queues count as one (measured better on final_scene)
         const bool merged = P.th_new == 0; // (the every-feature presets keep it merged: measured best on final_scene, tools/tune.py)
@@ -718,6 +745,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 }
                 PROF_MARK(8);
                 V3 attenuation = tex;
+                // what gets parked: the material's index where its attenuation is a constant of the material, else the colour
+                const uint32_t park_id = (!HAS_TEXTURES || (P.ids_ok != 0u && (mk == RT_MATERIAL_METAL || m->solid != 0u))) ? mat : ID_COLOUR;
                 bool unit_attenuation = false;
                 V3 new_dir = normal;
                 if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
@@ -751,11 +780,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     new_dir = normalize(rs);
                 }
                 if (!path_done) {
-                    if (!unit_attenuation) {
-                        double *slot = att + n_att * att_stride;
-                        slot[0] = attenuation.x; slot[1] = attenuation.y; slot[2] = attenuation.z;
-                        n_att++;
-                    }
+                    if (!unit_attenuation) park(park_id, attenuation);
                     depth--;
                     if (depth <= 0) { // the next ray_color call returns Color::ZERO at once
                         path_done = true;
@@ -769,10 +794,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
                         // a light: the emitted colour is parked like one more attenuation and the path ends on Color::ONE
                         // (emitted * 1.0 is emitted, bit for bit), so the chain of products is written once, in ST_NEWJOB
-                        // (nothing is stored: the two registers the path-end round reads first are filled here)
-                        if (n_att > 0) { const double *below = att + (n_att - 1u) * att_stride; d = v3(below[0], below[1], below[2]); }
-                        o = result;
-                        n_att++;
+                        park(park_id, result);
                         stage = ST_NEWJOB + TERM_ONE;
                     } else {
                         stage = ST_NEWJOB + TERM_ZERO; // absorbed, out of depth, or a black emitter
@@ -791,25 +813,30 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 V3 result = v3(0.0, 0.0, 0.0);
                 if (term != TERM_ZERO) {
                     result = term == TERM_BACKGROUND ? from(P.cam.background) : v3(1.0, 1.0, 1.0);
-                    // the last two parked attenuations are in o and d already (prefetch_parked); below them, up to CHAIN per trip,
-                    // their loads issued together (one memory latency, not CHAIN); the products still run one after the other, last
-                    // parked first.  A zero terminal stays zero (attenuations are finite).
+                    // the parked attenuations, last parked first.  The newest four indices sit at fixed places of the two registers:
+                    // their colours are fetched together and multiplied on one after the other (a level the path does not have reads
+                    // Color::ONE); older ones come from att_ids, up to CHAIN per trip.  A zero terminal stays zero (attenuations are finite).
                     if (result.x != 0.0 || result.y != 0.0 || result.z != 0.0) {
-                        if (n_att > 0) result = o * result;
-                        if (n_att > 1) result = d * result;
-                        n_att = n_att > 2u ? n_att - 2u : 0u;
-                        while (n_att > 0) {
+                        V3 newest[IDS_IN_REGS];
+                    #pragma unroll
+                        for (uint32_t k = 0; k < IDS_IN_REGS; ++k) {
+                            const uint32_t id = (k & 1u) ? ids[k >> 1] >> 16 : ids[k >> 1] & 0xffffu;
+                            newest[k] = parked_colour(n_att > k ? id : P.id_one, n_att > k ? n_att - 1u - k : 0u);
+                        }
+                    #pragma unroll
+                        for (uint32_t k = 0; k < IDS_IN_REGS; ++k) result = newest[k] * result;
+                        uint32_t level = n_att > IDS_IN_REGS ? n_att - IDS_IN_REGS : 0u; // levels [0, level) are in att_ids
+                        while (level > 0) {
                             V3 parked[CHAIN];
                     #pragma unroll
                             for (uint32_t j = 0; j < CHAIN; ++j) {
-                                const uint32_t level = n_att > j ? n_att - 1u - j : 0u;
-                                const double *slot = att + level * att_stride;
-                                parked[j] = v3(slot[0], slot[1], slot[2]);
+                                const uint32_t lv = level > j ? level - 1u - j : 0u;
+                                const uint32_t id = level > j ? att_ids[lv * att_lanes + gtid] : P.id_one;
+                                parked[j] = parked_colour(id, lv);
                             }
                     #pragma unroll
-                            for (uint32_t j = 0; j < CHAIN; ++j)
-                                if (n_att > j) result = parked[j] * result;
-                            n_att = n_att > CHAIN ? n_att - CHAIN : 0;
+                            for (uint32_t j = 0; j < CHAIN; ++j) result = parked[j] * result;
+                            level = level > CHAIN ? level - CHAIN : 0u;
                         }
                     }
                 }

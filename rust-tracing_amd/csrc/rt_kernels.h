@@ -38,7 +38,11 @@ struct KParams {
     const double *srgb_lut;
     double *out;
     double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
-    double *att_stack;              // [max_depth + 1][n_threads][3]: attenuations of the current path
+    double *att_stack;              // [max_depth + 1][3][n_threads]: parked attenuations that are a texture's value (path_kernel); the pool
+                                    // kernel parks every attenuation here, as [max_depth + 1][n_threads][3]
+    uint32_t *att_ids;              // [max_depth + 1 - 8][n_threads]: parked material indices that no longer fit the lane's registers
+    uint32_t ids_ok;                // 1: material indices fit 16 bits (else every attenuation is parked as a colour, by a kernel with textures)
+    uint32_t id_one;                // index of the material table's extra last entry, whose albedo is Color::ONE
     uint32_t *job_counter;
     unsigned long long *counters;   // rt_counters as 10 u64, then per profile slot (9): rounds, active lanes, cycles; or null
     rt_camera cam;
