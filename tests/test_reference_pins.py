@@ -131,3 +131,57 @@ def test_gpu_converged_final_scene_matches_the_reference_screenshot(rt, gpu):
         assert np.abs(rel[fixed]).max() < 0.05 and np.sqrt((rel[fixed] ** 2).mean()) < 0.015, (scene_seed, np.abs(rel[fixed]).max())
         compare(sums, spp, shot, mean_tol=0.04, rms_tol=0.09, max_tol=0.22, coarse=4)
         compare(sums, spp, shot, mean_tol=0.04, rms_tol=0.06, max_tol=0.13, coarse=6)
+
+
+# ---- pixel-level pins: cornell_box.png / cornell_smoke.png (src/main.rs:344-506), 600x600, depth 8, no build-time randomness ----------
+# Fixture tests/golden/reference_pixel_pins.npz (made by tests/golden/make_reference_pixel_pins.py, which also says why the filter is
+# 7x7: the screenshots carry 4-6 sRGB levels of Monte-Carlo noise per pixel themselves).  What this pins that block means cannot: the
+# silhouettes of the two rotated boxes, the rectangle of the light, the shadow boundaries and the room's corners to one pixel —
+# i.e. Camera::new, RotateY's signs, Translate's offsets, Quad::hit's edges — and the shading between them to 3 levels.
+PINS = np.load(Path(__file__).parent / "golden" / "reference_pixel_pins.npz")
+
+
+def pixel_pin_stats(rt, sums, spp, name):
+    from scipy.ndimage import binary_dilation, uniform_filter
+    srgb = rt.resolve_rgb8_host(600, 600, spp, sums).astype(np.float64)  # color_to_rgb (src/color.rs:12-19), the host's output stage
+    box = lambda a, k: uniform_filter(a, size=(k, k, 1), mode="nearest")
+    d = box(srgb, 7)[::2, ::2] - PINS[f"{name}_box7"].astype(np.float64) / 4.0
+    lum = box(srgb, 3) @ np.array([0.2126, 0.7152, 0.0722])
+    gx, gy = np.zeros_like(lum), np.zeros_like(lum)
+    gx[:, 1:-1] = lum[:, 2:] - lum[:, :-2]
+    gy[1:-1, :] = lum[2:, :] - lum[:-2, :]
+    hi, lo = float(PINS["hi"]), float(PINS["lo"])
+    masks = lambda t: np.stack([gx > t, gx < -t, gy > t, gy < -t])
+    unpack = lambda key: np.unpackbits(PINS[f"{name}_{key}"])[:4 * 600 * 600].reshape(4, 600, 600).astype(bool)
+    near = lambda m: np.stack([binary_dilation(x, structure=np.ones((3, 3), dtype=bool)) for x in m])  # within one pixel, diagonals included
+    ours_strong, ours_weak, ref_strong, ref_weak = masks(hi), masks(lo), unpack("strong"), unpack("weak")
+    return {"within": lambda tol: float((np.abs(d).max(axis=2) <= tol).mean()), "rms": float(np.sqrt((d ** 2).mean())),
+            "ref_edges": int(ref_strong.sum()), "ref_edges_found": float((ref_strong & near(ours_weak)).sum() / ref_strong.sum()),
+            "our_edges": int(ours_strong.sum()), "our_edges_found": float((ours_strong & near(ref_weak)).sum() / max(1, ours_strong.sum()))}
+
+
+def test_oracle_puts_the_cornell_box_edges_where_the_reference_screenshot_has_them(rt, oracle):
+    """256 spp of the oracle (half a minute): enough for the edge positions — every strong luminance edge of the screenshot within one
+    pixel of one of ours and the other way round.  The filtered image only gets a sanity bound here: at 256 spp a pixel carries 23
+    levels of noise (and sits lower on average: the gamma curve is concave), the 7x7 filter leaves 5 of them.  The tight comparison is
+    the GPU test below; the GPU frame equals this oracle's bit for bit."""
+    spp = 256
+    hs = rt.HostScene(int(PINS["cornell_box_scene"]), spp=spp)
+    assert (hs.width, hs.height, hs.camera.max_depth) == (600, 600, 8)
+    st = pixel_pin_stats(rt, oracle.render(hs, rt.render_params(seed=7)), spp, "cornell_box")
+    assert st["ref_edges"] > 1000 and st["ref_edges_found"] >= 0.97 and st["our_edges_found"] >= 0.97, st
+    assert st["within"](20.0) >= 0.98 and st["rms"] < 8.0, (st["within"](20.0), st["rms"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke"])
+def test_gpu_render_matches_the_reference_screenshot_pixel_by_pixel(rt, gpu, name):
+    """16384 spp at the in-code camera (600x600, depth 8): after the 7x7 filter at least 99 % of the pixels within +-3 sRGB levels of the
+    screenshot, and the strong luminance edges of either image within one pixel of an edge of the other."""
+    spp = 16384
+    hs = rt.HostScene(int(PINS[f"{name}_scene"]), spp=spp)
+    assert (hs.width, hs.height, hs.camera.max_depth) == (600, 600, 8)
+    st = pixel_pin_stats(rt, rt.DeviceScene(hs).render(rt.render_params(seed=7)), spp, name)
+    print(name, {k: (v if not callable(v) else [round(v(t), 5) for t in (1.0, 2.0, 3.0)]) for k, v in st.items()})
+    assert st["within"](3.0) >= 0.99, (st["within"](3.0), st["rms"])
+    assert st["ref_edges"] > 1000 and st["ref_edges_found"] >= 0.99 and st["our_edges_found"] >= 0.99, st
