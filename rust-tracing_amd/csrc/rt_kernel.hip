@@ -252,7 +252,6 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     bool jobs_left = true;
 
     const uint32_t n_nodes = P.n_nodes;
-    const int32_t w = P.cam.image_width, h = P.cam.image_height;
 
     auto refresh_ray32 = [&]() {
         if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : 16u, P.box_extent);
@@ -807,12 +806,21 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         }
         if (run == ST_NEWJOB || (run == ST_SHADE && merged)) {
             // ---------------- finish a path, take the next job, Camera::get_ray ----------------
+            // What this block alone reads of the parameter block — the camera (44 scalar registers' worth of doubles), the seed, the job
+            // arithmetic — is fetched from the kernel-argument segment HERE, through a pointer the optimiser cannot look behind.  Read as
+            // plain members of P these values are loaded once at the kernel's start and then have to sit in scalar registers through
+            // every round of every other stage; there are ~100 of those registers, the spill goes to VGPR lanes, and what got evicted was
+            // what the hot loops use: the every-feature kernel reloaded the record table's base address with a v_readlane per visit.
+            // (SGPR spills: spheres kernel 78 -> 2, quads + frames 67 -> 8, every-feature 160 -> 46; C2 +3.0 %, C3 +3.8 %, C4 +1.1 %.)
+            const KParams __attribute__((address_space(4))) *KP =
+                (const KParams __attribute__((address_space(4))) *)(uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(KP));
             const bool here = stage - ST_NEWJOB < 4u;
             const uint32_t term = stage - ST_NEWJOB;
             if (here && term != TERM_STORED) {
                 V3 result = v3(0.0, 0.0, 0.0);
                 if (term != TERM_ZERO) {
-                    result = term == TERM_BACKGROUND ? from(P.cam.background) : v3(1.0, 1.0, 1.0);
+                    result = term == TERM_BACKGROUND ? v3(KP->cam.background.x, KP->cam.background.y, KP->cam.background.z) : v3(1.0, 1.0, 1.0);
                     // the parked attenuations, last parked first.  The newest four indices sit at fixed places of the two registers:
                     // their colours are fetched together and multiplied on one after the other (a level the path does not have reads
                     // Color::ONE); older ones come from att_ids, up to CHAIN per trip.  A zero terminal stays zero (attenuations are finite).
@@ -840,7 +848,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         }
                     }
                 }
-                double *dst = P.samples + (size_t)job * 3u;
+                double *dst = KP->samples + (size_t)job * 3u;
                 dst[0] = result.x; dst[1] = result.y; dst[2] = result.z;
                 stage = ST_NEWJOB + TERM_STORED;
             }
@@ -859,15 +867,15 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // wave's last grab, the tail of the launch, is short although the early grabs are large.  Any sizes tile the job
                     // range, so a stale estimate is harmless.  (No extra look at the counter: 4096 waves reading and adding to one
                     // word already approach what one L2 line serves — MI355X_MICROARCH.md "dequeue": ~88 per microsecond.)
-                    uint32_t grab = (uint32_t)((float)jobs_seen_left * P.grab_taper) & ~63u;
-                    grab = grab < P.jobs_per_grab ? grab : P.jobs_per_grab;
+                    uint32_t grab = (uint32_t)((float)jobs_seen_left * KP->grab_taper) & ~63u;
+                    grab = grab < KP->jobs_per_grab ? grab : KP->jobs_per_grab;
                     grab = grab < MIN_JOBS_PER_GRAB ? MIN_JOBS_PER_GRAB : grab;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.job_counter, grab);
+                    if (lane == 0) base = atomicAdd(KP->job_counter, grab);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    jobs_seen_left = base + grab < P.n_jobs ? P.n_jobs - (base + grab) : 0u;
-                    if (base >= P.n_jobs) { jobs_left = false; }
-                    else { new_base = base; new_avail = (base + grab < P.n_jobs ? base + grab : P.n_jobs) - base; }
+                    jobs_seen_left = base + grab < KP->n_jobs ? KP->n_jobs - (base + grab) : 0u;
+                    if (base >= KP->n_jobs) { jobs_left = false; }
+                    else { new_base = base; new_avail = (base + grab < KP->n_jobs ? base + grab : KP->n_jobs) - base; }
                 }
                 const uint32_t avail = old_avail + new_avail;
                 const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
@@ -879,25 +887,25 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         const uint32_t row = job >> 6;
                         // n / d for n < 2^27 as trunc((n + 0.5) * (1 / d)) in f64: (n + 0.5) / d is at least 0.5 / d away from an
                         // integer, far more than the 2^-52 relative error of the product — exact, and 4 instructions, not 25
-                        const uint32_t lt = (uint32_t)(((double)row + 0.5) * P.inv_n_samples), s_rel = row - lt * P.n_samples;
-                        const uint32_t k = lt * (uint32_t)P.shard_count + (uint32_t)P.shard_index;
-                        const uint32_t tile_row = (uint32_t)(((double)k + 0.5) * P.inv_tiles_x), tile_col = k - tile_row * (uint32_t)P.tiles_x;
+                        const uint32_t lt = (uint32_t)(((double)row + 0.5) * KP->inv_n_samples), s_rel = row - lt * KP->n_samples;
+                        const uint32_t k = lt * (uint32_t)KP->shard_count + (uint32_t)KP->shard_index;
+                        const uint32_t tile_row = (uint32_t)(((double)k + 0.5) * KP->inv_tiles_x), tile_col = k - tile_row * (uint32_t)KP->tiles_x;
                         const int32_t i = (int32_t)tile_col * RT_TILE_W + (int32_t)(p64 & 7u);
                         const int32_t j = (int32_t)tile_row * RT_TILE_H + (int32_t)(p64 >> 3);
-                        if (i < w && j < h) {
-                            const uint32_t pixel = (uint32_t)j * (uint32_t)w + (uint32_t)i; // screen_pos (src/renderer.rs:32-33)
-                            rng.start(P.seed_mixed, pixel, (uint32_t)P.sample_begin + s_rel);
+                        if (i < KP->cam.image_width && j < KP->cam.image_height) {
+                            const uint32_t pixel = (uint32_t)j * (uint32_t)KP->cam.image_width + (uint32_t)i; // screen_pos (src/renderer.rs:32-33)
+                            rng.start(KP->seed_mixed, pixel, (uint32_t)KP->sample_begin + s_rel);
                             // Camera::get_ray (src/camera.rs:112-137)
-                            const rt_camera &cam = P.cam;
-                            const V3 du = from(cam.pixel_delta_u), dv = from(cam.pixel_delta_v);
-                            const V3 pixel_center = from(cam.pixel00_loc) + du * (double)i + dv * (double)j;
+                            const rt_camera __attribute__((address_space(4))) &cam = KP->cam;
+                            const V3 du = v3(cam.pixel_delta_u.x, cam.pixel_delta_u.y, cam.pixel_delta_u.z), dv = v3(cam.pixel_delta_v.x, cam.pixel_delta_v.y, cam.pixel_delta_v.z);
+                            const V3 pixel_center = v3(cam.pixel00_loc.x, cam.pixel00_loc.y, cam.pixel00_loc.z) + du * (double)i + dv * (double)j;
                             const double px = -0.5 + rng.random();
                             const double py = -0.5 + rng.random();
                             if (COUNT) cn.rng_draws += 2;
                             const V3 pixel_sample = pixel_center + (du * px + dv * py);
                             V3 ro;
                             if (cam.defocus_angle <= 0.0) {
-                                ro = from(cam.center);
+                                ro = v3(cam.center.x, cam.center.y, cam.center.z);
                             } else { // random_in_unit_disk (src/vec3.rs:77-88)
                                 double dx, dy;
                                 for (;;) {
@@ -906,13 +914,13 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                                     if (COUNT) cn.rng_draws += 2;
                                     if (dx * dx + dy * dy + 0.0 * 0.0 < 1.0) break;
                                 }
-                                ro = from(cam.center) + from(cam.defocus_disk_u) * dx + from(cam.defocus_disk_v) * dy;
+                                ro = v3(cam.center.x, cam.center.y, cam.center.z) + v3(cam.defocus_disk_u.x, cam.defocus_disk_u.y, cam.defocus_disk_u.z) * dx + v3(cam.defocus_disk_v.x, cam.defocus_disk_v.y, cam.defocus_disk_v.z) * dy;
                             }
                             o = ro;
                             d = pixel_sample - ro;
                             time = rng.random();
                             if (COUNT) cn.rng_draws += 1;
-                            depth = P.max_depth;
+                            depth = KP->max_depth;
                             n_att = 0;
                             if (COUNT) cn.samples++;
                             start_query = true; // of the camera ray
