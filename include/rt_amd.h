@@ -276,6 +276,14 @@ typedef struct rt_scene_options {
     int32_t pool;                /* -1 default (off); 1: render with the pool kernel where the scene allows it (LDS-resident, own
                                     trees): paths move between walking lanes and full-width shading rounds through a slot pool in
                                     the LDS (DESIGN.md "Ray compaction across stages"); 0: never */
+    int32_t flat_max;            /* own trees: a frame of at most this many primitives of one kind keeps them in one leaf under its root
+                                    (0: off; -1: default, 8) */
+    /* how the walk of the library's own trees starts and ends its queries (each -1: default) */
+    int32_t start_shortcut;      /* 1: a query starts with the primitives of a leaf under the root that spans the scene */
+    int32_t defer_instances;     /* 1: the world frame's Translate / RotateY subtrees are walked after the world's own tree */
+    int32_t seq_lookahead;       /* 1: scenes with media: a query that cannot reach a later step of the world's sequence ends it early */
+    int32_t slow_min, slow_age;  /* hits on a noise texture wait in the shade stage for slow_min of their kind, at most slow_age shade
+                                    rounds (slow_min 1: nobody waits) */
     int32_t _reserved;
 } rt_scene_options;
 void rt_scene_options_init(rt_scene_options *options);

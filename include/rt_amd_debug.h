@@ -81,6 +81,13 @@ typedef struct rt_debug_ordered {
     uint32_t *steps, *media;
 } rt_debug_ordered;
 int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
+/* ... with the tree options of `options` (leaf_max, flat_max; NULL: the process defaults) */
+int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options *options, rt_debug_ordered *io);
+
+/* Which kernel the calling thread's last render launched: out[0] = path slots of the pool kernel (0: path_kernel rendered —
+ * also when the pool kernel was asked for and the scene did not qualify), out[1] = LDS level, out[2] = workgroup threads,
+ * out[3] = workgroups. */
+int rt_debug_last_launch(uint32_t out[4]);
 
 /* Profiling hook: where the last rt_render_device_counted call's waves spent their time.  For each scheduler stage
  * (box, sphere, quad, other, shade, new-job): rounds run, lanes active summed over those rounds, shader cycles (s_memtime)

@@ -170,11 +170,13 @@ class SceneCreateOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("walk", C.c_int32), ("leaf_max", C.c_int32), ("refit", C.c_int32),
                 ("use_lds", C.c_int32), ("th_prim", C.c_int32), ("th_other", C.c_int32), ("th_shade", C.c_int32),
                 ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("pool", C.c_int32),
-                ("_reserved", C.c_int32)]
+                ("flat_max", C.c_int32), ("start_shortcut", C.c_int32), ("defer_instances", C.c_int32),
+                ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("_reserved", C.c_int32)]
 
 
 def scene_options(**kw) -> "SceneCreateOptions":
-    """rt_scene_options_init, then the given fields (walk=, leaf_max=, refit=, use_lds=, th_*=, sample_buffer_bytes=)."""
+    """rt_scene_options_init, then the given fields (walk=, leaf_max=, flat_max=, refit=, use_lds=, th_*=, sample_buffer_bytes=,
+    start_shortcut=, defer_instances=, seq_lookahead=, slow_min=, slow_age=)."""
     o = SceneCreateOptions()
     amd_lib().rt_scene_options_init(C.byref(o))
     for k, v in kw.items():
@@ -235,9 +237,11 @@ RT_AMD_DEBUG_SYMBOLS = {
     "rt_debug_compiled_nodes": (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.POINTER(DebugNode), C.c_int64,
                                           C.POINTER(C.c_int64)]),
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "rt_debug_last_launch": (C.c_int, [C.POINTER(C.c_uint32)]),
     "rt_debug_set_traversal": (C.c_int, [C.c_int32, C.c_int32]),
     "rt_debug_set_walk_shortcuts": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_debug_ordered_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_debug_ordered_layout_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_debug_set_tuning": (C.c_int, [C.c_int32] * 6),
 }
 
@@ -281,11 +285,14 @@ class DebugOrdered(C.Structure):
                 ("steps", C.c_void_p), ("media", C.c_void_p)]
 
 
-def debug_ordered_layout(host_scene) -> dict:
-    """rt_debug_ordered_layout: the scene compiler's ordered layout (numpy arrays), no device needed."""
+def debug_ordered_layout(host_scene, **option_fields) -> dict:
+    """rt_debug_ordered_layout_ex: the scene compiler's ordered layout (numpy arrays), no device needed; leaf_max= / flat_max= as
+    rt_scene_options has them."""
     import numpy as np
     io = DebugOrdered()
-    _check(amd_lib().rt_debug_ordered_layout(C.addressof(host_scene.desc), C.addressof(io)), "rt_debug_ordered_layout")
+    opts = scene_options(**option_fields) if option_fields else None
+    call = lambda: amd_lib().rt_debug_ordered_layout_ex(C.addressof(host_scene.desc), C.addressof(opts) if opts is not None else None, C.addressof(io))
+    _check(call(), "rt_debug_ordered_layout")
     nodes = np.zeros((max(io.n_nodes, 1), 16), dtype=np.uint32)
     spheres = np.zeros((max(io.n_spheres, 1), 9)); quads = np.zeros((max(io.n_quads, 1), 10))
     insts = np.zeros((max(io.n_instances, 1), 8))
@@ -294,10 +301,17 @@ def debug_ordered_layout(host_scene) -> dict:
     io.cap_steps, io.cap_media = len(steps), len(media)
     io.nodes, io.spheres, io.quads, io.instances = (a.ctypes.data for a in (nodes, spheres, quads, insts))
     io.steps, io.media = steps.ctypes.data, media.ctypes.data
-    _check(amd_lib().rt_debug_ordered_layout(C.addressof(host_scene.desc), C.addressof(io)), "rt_debug_ordered_layout")
+    _check(call(), "rt_debug_ordered_layout")
     return {"ordered": bool(io.ordered), "root": int(io.root), "stack_entries": int(io.stack_entries),
             "nodes": nodes[:io.n_nodes], "spheres": spheres[:io.n_spheres], "quads": quads[:io.n_quads],
             "instances": insts[:io.n_instances], "steps": steps[:io.n_steps], "media": media[:io.n_media]}
+
+
+def debug_last_launch() -> dict:
+    """rt_debug_last_launch: which kernel this thread's last render ran (pool_slots 0: path_kernel)."""
+    buf = (C.c_uint32 * 4)()
+    _check(amd_lib().rt_debug_last_launch(buf), "rt_debug_last_launch")
+    return {"pool_slots": int(buf[0]), "lds_level": int(buf[1]), "threads": int(buf[2]), "grid": int(buf[3])}
 
 
 def debug_stage_profile() -> dict:

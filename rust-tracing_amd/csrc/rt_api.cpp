@@ -12,6 +12,7 @@ using namespace rtapi;
 namespace rtapi {
 
 thread_local std::string g_last_error;
+thread_local uint32_t g_last_launch[4] = {0, 0, 0, 0};
 std::mutex g_stage_profile_mu;
 unsigned long long g_stage_profile[PROF_SLOTS * 3] = {0};
 
@@ -24,7 +25,7 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
-    env("RT_POOL", pool); env("RT_POOL_CHECK", pool_check); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
+    env("RT_POOL", pool); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_FLAT_MAX")) ordered_options.flat_max = (uint32_t)atoi(e);
@@ -170,6 +171,11 @@ Tuning effective_tuning(const rt_scene *scene) {
         if (th[k] >= 0 && tn.forced[k] < 0) tn.forced[k] = th[k];
     if (o.sample_buffer_bytes > 0) tn.sample_buffer_bytes = (size_t)o.sample_buffer_bytes;
     if (o.pool >= 0) tn.pool = o.pool;
+    if (o.start_shortcut >= 0) tn.start_shortcut = o.start_shortcut;
+    if (o.defer_instances >= 0) tn.defer = o.defer_instances;
+    if (o.seq_lookahead >= 0) tn.seq_lookahead = o.seq_lookahead;
+    if (o.slow_min >= 1) tn.slow_min = o.slow_min;
+    if (o.slow_age >= 0) tn.slow_age = o.slow_age;
     return tn;
 }
 
@@ -457,6 +463,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
     HIP_TRY(hipEventRecord(ws.ev_done, stream));
+    g_last_launch[0] = pool_slots; g_last_launch[1] = (uint32_t)lds; g_last_launch[2] = (uint32_t)threads; g_last_launch[3] = (uint32_t)grid;
     if (pooled && tn.pool_prof != 0) { // RT_POOL_PROF=1: where the pool kernel's waves spent their cycles (stderr)
         HIP_TRY(hipStreamSynchronize(stream));
         unsigned long long c[30];
@@ -469,7 +476,8 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             if (c[q * 3 + 1]) fprintf(stderr, "  %-14s cycles %5.1f %%  rounds %10llu  lanes/round %5.1f  cycles/round %8.1f\n", names[q], 100.0 * (double)c[q * 3] / (double)total,
                     c[q * 3 + 1], (double)c[q * 3 + 2] / (double)c[q * 3 + 1], (double)c[q * 3] / (double)c[q * 3 + 1]);
     }
-    if (pooled && tn.pool_check != 0) { // RT_POOL_CHECK=1 (tests): wait, and turn the pool kernel's give-up flag into an error
+    if (pooled) { // a pool-kernel launch that stopped itself (idle watchdog, slot sanity checks) left an incomplete frame: always an error
+        // (the pool kernel is an opt-in experiment: the wait this costs is its own)
         HIP_TRY(hipStreamSynchronize(stream));
         for (int h = 0; h < (pipelined ? 2 : 1); ++h) {
             uint32_t flag = 0;
@@ -532,6 +540,7 @@ void rt_scene_options_init(rt_scene_options *o) {
     o->th_prim = o->th_other = o->th_shade = o->th_box = o->th_new = -1;
     o->sample_buffer_bytes = 0;
     o->pool = -1;
+    o->flat_max = o->start_shortcut = o->defer_instances = o->seq_lookahead = o->slow_min = o->slow_age = -1;
 }
 
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) { return rt_scene_create_ex(desc, device, nullptr, out_scene); }
@@ -553,6 +562,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     const bool refit = opt.refit >= 0 ? opt.refit != 0 : tn.refit != 0;
     OrderedOptions oopt = tn.ordered_options;
     if (opt.leaf_max > 0) oopt.leaf_max = (uint32_t)opt.leaf_max < OREF_MAX_LEAF ? (uint32_t)opt.leaf_max : OREF_MAX_LEAF;
+    if (opt.flat_max >= 0) oopt.flat_max = (uint32_t)opt.flat_max;
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, refit);

@@ -17,6 +17,7 @@ namespace rtapi {
 using namespace rtd;
 using namespace rtk;
 
+extern thread_local uint32_t g_last_launch[4]; // of the calling thread's last render: pool slots (0: path_kernel), LDS level, workgroup threads, grid
 int fail(int status, const std::string &msg); // sets rt_last_error() of the calling thread, returns `status`
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -72,7 +73,6 @@ struct Tuning {
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     int pool = 0;          // 1: ordered LDS-resident scenes render with the pool kernel (ray compaction across stages; RT_POOL)
     int pool_prof = 0;     // ... 1: the instrumented variant; prints a per-section cycle profile to stderr after every render (RT_POOL_PROF)
-    int pool_check = 0;    // ... 1: every render waits for its launches and reports a launch that flagged itself (RT_POOL_CHECK; tests)
     int pool_aux = -1, pool_want_words = 8; // ... small tables in the LDS too: 1 yes, 0 no, -1 only if the pool still gets this many words
     int pool_service = 2;  // ... service waves per workgroup (RT_POOL_SERVICE)
     int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)

@@ -44,12 +44,19 @@ int rt_debug_set_walk_shortcuts(int32_t flat_max, int32_t start_shortcut, int32_
     return RT_OK;
 }
 
-int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) {
+int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) { return rt_debug_ordered_layout_ex(desc, nullptr, io); }
+
+int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options *options, rt_debug_ordered *io) {
     if (!desc || !io) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: null argument");
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, true);
-        build_ordered(cs, tuning_snapshot().ordered_options);
+        OrderedOptions oopt = tuning_snapshot().ordered_options;
+        if (options && options->struct_size >= sizeof(rt_scene_options)) {
+            if (options->leaf_max > 0) oopt.leaf_max = (uint32_t)options->leaf_max < OREF_MAX_LEAF ? (uint32_t)options->leaf_max : OREF_MAX_LEAF;
+            if (options->flat_max >= 0) oopt.flat_max = (uint32_t)options->flat_max;
+        }
+        build_ordered(cs, oopt);
     } catch (const CompileError &e) {
         return fail(e.status, e.what());
     } catch (const std::exception &e) {
@@ -150,6 +157,12 @@ int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_n
             }
         }
     }
+    return RT_OK;
+}
+
+int rt_debug_last_launch(uint32_t out[4]) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_last_launch: null argument");
+    for (int k = 0; k < 4; ++k) out[k] = g_last_launch[k];
     return RT_OK;
 }
 

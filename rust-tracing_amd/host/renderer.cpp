@@ -39,7 +39,8 @@ std::vector<double> render_sums(const Camera &camera, const Hittable &world, con
     // HBM; at the end of a pass ONE grouped RCCL exchange brings the buffers to device 0 over xGMI, which reassembles the frame and
     // hands it to the host in one copy.  If RCCL cannot be loaded the frame travels through host memory instead (below).
     std::vector<rt_comm *> comms((size_t)ngpu, nullptr);
-    const bool device_route = rt_comm_create_all(ngpu, nullptr, comms.data()) == RT_OK;
+    // (one GPU: nothing to gather — no communicator, no RCCL: the frame comes back through rt_render's own copy, below)
+    const bool device_route = ngpu > 1 && rt_comm_create_all(ngpu, nullptr, comms.data()) == RT_OK;
     if (device_route) {
         const int64_t stride = rt_out_size(w, h, RT_OUT_TILES, 0, ngpu);
         std::vector<void *> tiles((size_t)ngpu, nullptr);
@@ -56,21 +57,25 @@ std::vector<double> render_sums(const Camera &camera, const Hittable &world, con
         for (int begin = 0; begin < spp; begin += pass) {
             const int end = begin + pass < spp ? begin + pass : spp;
             std::vector<std::string> errors((size_t)ngpu);
-            std::vector<std::thread> workers;
-            for (int g = 0; g < ngpu; ++g) {
-                workers.emplace_back([&, g]() { // one host thread per device: render, then this rank's part of the gather
-                    rt_render_params p{};
-                    p.seed = opt.seed; p.sample_begin = begin; p.sample_end = end; p.max_depth = cam.max_depth;
-                    p.accumulate = begin > 0 ? 1 : 0; // the tile buffers keep the running sums between passes
-                    p.shard_index = g; p.shard_count = ngpu; p.out_layout = RT_OUT_TILES; p.device = g;
-                    if (rt_render_device(scenes[(size_t)g], &cam, &p, static_cast<double *>(tiles[(size_t)g]), nullptr) != RT_OK ||
-                        rt_gather_tiles_device(comms[(size_t)g], w, h, 8, tiles[(size_t)g], g == 0 ? gathered : nullptr, 0, nullptr) != RT_OK)
-                        errors[(size_t)g] = rt_last_error();
-                });
-            }
-            for (auto &t : workers) t.join();
-            for (const auto &e : errors)
-                if (!e.empty()) { cleanup(); throw std::runtime_error("render: " + e); }
+            auto on_every_device = [&](auto &&fn) { // one host thread per device
+                std::vector<std::thread> workers;
+                for (int g = 0; g < ngpu; ++g) workers.emplace_back([&, g]() { if (fn(g) != RT_OK) errors[(size_t)g] = rt_last_error(); });
+                for (auto &t : workers) t.join();
+                for (const auto &e : errors)
+                    if (!e.empty()) { cleanup(); throw std::runtime_error("render: " + e); }
+            };
+            // Two phases with a join in between: a rank enters the grouped exchange only when EVERY rank has rendered — a rank that
+            // failed and stayed out would leave its peers' ncclSend / ncclRecv pending for ever (and cleanup() waiting on them).
+            on_every_device([&](int g) {
+                rt_render_params p{};
+                p.seed = opt.seed; p.sample_begin = begin; p.sample_end = end; p.max_depth = cam.max_depth;
+                p.accumulate = begin > 0 ? 1 : 0; // the tile buffers keep the running sums between passes
+                p.shard_index = g; p.shard_count = ngpu; p.out_layout = RT_OUT_TILES; p.device = g;
+                return rt_render_device(scenes[(size_t)g], &cam, &p, static_cast<double *>(tiles[(size_t)g]), nullptr);
+            });
+            on_every_device([&](int g) {
+                return rt_gather_tiles_device(comms[(size_t)g], w, h, 8, tiles[(size_t)g], g == 0 ? gathered : nullptr, 0, nullptr);
+            });
             if (rt_tiles_to_frame_device(w, h, ngpu, static_cast<const double *>(gathered), static_cast<double *>(frame), nullptr) != RT_OK ||
                 rt_device_download(0, sums.data(), frame, (int64_t)sums.size() * (int64_t)sizeof(double), nullptr) != RT_OK) {
                 const std::string msg = rt_last_error(); cleanup(); throw std::runtime_error("render: " + msg);

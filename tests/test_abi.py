@@ -104,3 +104,38 @@ def test_ctypes_structs_match_the_c_layout(rt, tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_the_rust_binding_in_integration_md_covers_rt_amd_h(rt):
+    """INTEGRATION.md's `extern "C"` block is the binding a maintainer of the reference would paste into src/gpu.rs (the seam is
+    render(), /root/reference src/renderer.rs:12 — no Rust toolchain here to compile it): every function include/rt_amd.h declares must
+    be in it with the same number of arguments, and every #[repr(C)] struct must list its C counterpart's fields in order."""
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "rt_amd.h").read_text(), flags=re.S)
+    c_arity = {}
+    for m in re.finditer(r"\b((?:rt)_\w+)\s*\(([^;{}]*?)\)\s*;", header):
+        name, args = m.group(1), m.group(2).strip()
+        if name in rt.RT_AMD_SYMBOLS:
+            c_arity[name] = 0 if args in ("", "void") else args.count(",") + 1
+    assert sorted(c_arity) == sorted(rt.RT_AMD_SYMBOLS)
+    text = (ROOT / "INTEGRATION.md").read_text()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    block = re.sub(r"//[^\n]*", "", block)
+    rust_arity = {}
+    for m in re.finditer(r"pub fn (rt_\w+)\s*\(([^)]*)\)", block):
+        args = m.group(2).strip()
+        rust_arity[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert sorted(rust_arity) == sorted(c_arity), (sorted(set(c_arity) - set(rust_arity)), sorted(set(rust_arity) - set(c_arity)))
+    assert rust_arity == c_arity, {n: (rust_arity[n], c_arity[n]) for n in c_arity if rust_arity[n] != c_arity[n]}
+    # struct fields, in order (names only: the types are checked against gcc through the ctypes mirrors above)
+    mirrors = {"rt_vec3": rt.Vec3, "rt_aabb": rt.Aabb, "rt_ref": rt.Ref, "rt_sphere": rt.Sphere, "rt_quad": rt.Quad, "rt_list": rt.List,
+               "rt_translate": rt.Translate, "rt_rotate_y": rt.RotateY, "rt_bvh_node": rt.BvhNode, "rt_bvh": rt.Bvh,
+               "rt_constant_medium": rt.ConstantMedium, "rt_material": rt.Material, "rt_texture": rt.Texture, "rt_perlin": rt.Perlin,
+               "rt_image": rt.Image, "rt_scene_desc": rt.SceneDesc, "rt_camera": rt.Camera, "rt_render_params": rt.RenderParams,
+               "rt_scene_options": rt.SceneCreateOptions, "rt_counters": rt.Counters, "rt_scene_stats": rt.SceneStats}
+    rust = re.sub(r"/\*.*?\*/", "", re.sub(r"//[^\n]*", "", text), flags=re.S)
+    for cname, cls in mirrors.items():
+        m = re.search(r"pub struct " + cname + r"\s*\{(.*?)\}", rust, flags=re.S)
+        assert m, f"INTEGRATION.md declares no struct {cname}"
+        fields = re.findall(r"pub (\w+)\s*:", m.group(1))
+        assert fields == [f for f, _ in cls._fields_], (cname, fields)

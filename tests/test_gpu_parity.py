@@ -196,15 +196,13 @@ def test_counters_match_the_oracle_in_tight_mode(rt, oracle, gpu):
     up to the refit; the ordered walk of the library's own trees (final_scene: a sequence of trees and media) must
     trace the same rays and draw the same numbers while testing far fewer boxes."""
     import torch
-    lib = rt.amd_lib()
-    try:
+    if True:
         for name in ("c2_random_balls_96x64_8spp_d50", "c3_cornell_box_64x64_16spp_d50", "c4_final_scene_64x64_8spp_d40"):
             hs = scene_cases.build(rt, name)
             params = rt.render_params(seed=4)
             want_img, want = oracle.render(hs, params, aabb_mode=oracle.ORC_AABB_TIGHT, want_counters=True)
             for ordered in (0, 2):
-                lib.rt_debug_set_traversal(ordered, -1)
-                ds = rt.DeviceScene(hs)
+                ds = rt.DeviceScene(hs, walk=rt.RT_WALK_OWN_TREES if ordered else rt.RT_WALK_REFERENCE_ORDER)
                 assert ds.stats()["ordered"] == (1 if ordered else 0)
                 d = torch.zeros(hs.width * hs.height * 3, dtype=torch.float64, device="cuda")
                 got = ds.render_device_counted(params, d.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -216,8 +214,10 @@ def test_counters_match_the_oracle_in_tight_mode(rt, oracle, gpu):
                     # one visit = one record (two box tests): fewer records than the reference walk tests boxes
                     assert 0 < got["node_visits"] <= 0.6 * want["node_visits"], (name, got["node_visits"], want["node_visits"])
                     # (primitive tests may exceed the reference walk's: a frame of a few primitives tests them all, and a query may
-                    # start with the leaf under the root without testing its box — rounds that the wave runs anyway)
-                    assert got["sphere_tests"] + got["quad_tests"] <= 3.0 * (want["sphere_tests"] + want["quad_tests"])
+                    # start with the leaf under the root without testing its box — rounds that the wave runs anyway
+                    # — Cornell: 49 quad tests per sample against 21; where neither applies the ordered walk tests no more than 1.5x)
+                    bound = 3.0 if "cornell" in name else 1.5
+                    assert got["sphere_tests"] + got["quad_tests"] <= bound * (want["sphere_tests"] + want["quad_tests"]), name
                     assert got["medium_visits"] <= want["medium_visits"] * 1.03 + 2
                     continue
                 # The kernel walks boxes refitted to the geometry (tighter than the reference's, which the oracle walks)
@@ -227,8 +227,6 @@ def test_counters_match_the_oracle_in_tight_mode(rt, oracle, gpu):
                     assert 0 <= got[key] <= want[key] * 1.03 + 2, (name, key, got[key], want[key])
                 # the kernel tests fewer boxes than the tree has pairs (nested BVH roots and list wrappers are merged)
                 assert 0 < got["node_visits"] <= want["node_visits"] * 1.03, (name, got["node_visits"], want["node_visits"])
-    finally:
-        lib.rt_debug_set_traversal(1, -1)
 
 
 def test_errors_are_reported_not_thrown(rt, gpu):

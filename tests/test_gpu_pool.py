@@ -23,6 +23,7 @@ def test_pool_kernel_matches_the_oracle(rt, oracle, gpu, name):
     ds = rt.DeviceScene(hs, walk=rt.RT_WALK_OWN_TREES, pool=1)
     assert ds.stats()["ordered"] == 1 and ds.stats()["lds_nodes"] > 0
     got = ds.render(params)
+    assert rt.debug_last_launch()["pool_slots"] >= 256, "the pool kernel did not run (silent fall-back to path_kernel)"
     assert (bits(got) == bits(want)).all()
 
 
@@ -33,6 +34,7 @@ def test_pool_kernel_on_hand_made_scenes(rt, oracle, gpu):
                   custom_scenes.single_sphere_scene(cam), custom_scenes.empty_frame_scene(cam), custom_scenes.many_spheres_scene(cam, 300)):
         want = oracle.render(scene, params)
         got = rt.DeviceScene(scene, walk=rt.RT_WALK_OWN_TREES, pool=1).render(params)
+        assert rt.debug_last_launch()["pool_slots"] >= 256
         assert (bits(got) == bits(want)).all()
 
 

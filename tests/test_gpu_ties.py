@@ -13,22 +13,19 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+WALKS = {2: "RT_WALK_OWN_TREES", 1: "RT_WALK_AUTO", 0: "RT_WALK_REFERENCE_ORDER"}  # per-scene options (rt_scene_options.walk)
+
+
 def check(rt, oracle, scene, what):
-    lib = rt.amd_lib()
     params = rt.render_params(seed=3)
     want = oracle.render(scene, params)
-    try:
-        for ordered in (2, 0):  # 2: own trees wherever the scene allows it; 0: reference order
-            lib.rt_debug_set_traversal(ordered, -1)
-            for leaf in ((1, 2, 4, 8) if ordered else (-1,)):
-                lib.rt_debug_set_traversal(-1, leaf)
-                ds = rt.DeviceScene(scene)
-                assert ds.stats()["ordered"] == (1 if ordered else 0)
-                got = ds.render(params)
-                bad = np.flatnonzero(bits(got) != bits(want))
-                assert bad.size == 0, f"{what}: ordered={ordered} leaf={leaf}: {bad.size} of {want.size} values differ, first at {bad[:4]}"
-    finally:
-        lib.rt_debug_set_traversal(1, 0)
+    for ordered in (2, 0):  # 2: own trees wherever the scene allows it; 0: reference order
+        for leaf in ((1, 2, 4, 8) if ordered else (0,)):
+            ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[ordered]), leaf_max=leaf)
+            assert ds.stats()["ordered"] == (1 if ordered else 0)
+            got = ds.render(params)
+            bad = np.flatnonzero(bits(got) != bits(want))
+            assert bad.size == 0, f"{what}: ordered={ordered} leaf={leaf}: {bad.size} of {want.size} values differ, first at {bad[:4]}"
 
 
 @pytest.mark.parametrize("order", [0, 1, 2])
@@ -74,12 +71,7 @@ def test_media_between_other_objects(rt, oracle, gpu, order):
 def test_medium_inside_a_frame_keeps_the_reference_walk(rt, oracle, gpu):
     cam = scene_cases.build(rt, "quads_64x64_8spp")
     scene = custom_scenes.media_scene(cam, 0, nested=True)
-    lib = rt.amd_lib()
-    lib.rt_debug_set_traversal(2, 0)
-    try:
-        assert rt.DeviceScene(scene).stats()["ordered"] == 0
-    finally:
-        lib.rt_debug_set_traversal(1, 0)
+    assert rt.DeviceScene(scene, walk=rt.RT_WALK_OWN_TREES).stats()["ordered"] == 0
     params = rt.render_params(seed=3)
     want = oracle.render(scene, params)
     got = rt.DeviceScene(scene).render(params)
@@ -91,17 +83,12 @@ def test_too_many_sequence_steps_fall_back_to_the_reference_walk(rt, oracle, gpu
     must see every medium's own boundary sphere."""
     cam = scene_cases.build(rt, "quads_64x64_8spp")
     scene = custom_scenes.many_media_scene(cam, 40)
-    lib = rt.amd_lib()
     params = rt.render_params(seed=3)
     want = oracle.render(scene, params)
-    try:
-        for ordered in (2, 1, 0):
-            lib.rt_debug_set_traversal(ordered, 0)
-            ds = rt.DeviceScene(scene)
-            assert ds.stats()["ordered"] == 0
-            assert (bits(ds.render(params)) == bits(want)).all(), f"ordered={ordered}"
-    finally:
-        lib.rt_debug_set_traversal(1, 0)
+    for ordered in (2, 1, 0):
+        ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[ordered]))
+        assert ds.stats()["ordered"] == 0
+        assert (bits(ds.render(params)) == bits(want)).all(), f"ordered={ordered}"
     check(rt, oracle, custom_scenes.many_media_scene(cam, 20), "41 steps")
 
 
@@ -131,19 +118,15 @@ def test_random_object_graphs(rt, oracle, gpu):
     cam = scene_cases.build(rt, "ragged_cornell_37x37_4spp")
     params = rt.render_params(seed=5)
     ordered_seen = 0
-    try:
-        for seed in range(40):
-            scene = custom_scenes.random_scene(cam, seed)
-            want = oracle.render(scene, params)
-            for ordered in (2, 0):
-                lib.rt_debug_set_traversal(ordered, 0)
-                ds = rt.DeviceScene(scene)
-                ordered_seen += ds.stats()["ordered"]
-                got = ds.render(params)
-                bad = np.flatnonzero(bits(got) != bits(want))
-                assert bad.size == 0, f"random scene {seed}, ordered={ds.stats()['ordered']}: {bad.size} of {want.size} values differ"
-    finally:
-        lib.rt_debug_set_traversal(1, 0)
+    for seed in range(40):
+        scene = custom_scenes.random_scene(cam, seed)
+        want = oracle.render(scene, params)
+        for ordered in (2, 0):
+            ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[ordered]))
+            ordered_seen += ds.stats()["ordered"]
+            got = ds.render(params)
+            bad = np.flatnonzero(bits(got) != bits(want))
+            assert bad.size == 0, f"random scene {seed}, ordered={ds.stats()['ordered']}: {bad.size} of {want.size} values differ"
     assert ordered_seen >= 30
 
 
@@ -160,7 +143,7 @@ def test_default_choice_of_the_walk(rt, gpu):
 @pytest.mark.parametrize("shortcuts", [(0, 0, 0, 0, 1, 0), (8, 0, 1, 1, 64, 3), (0, 1, 0, 1, 2, 1000), (3, 1, 1, 0, 4, 32)])
 def test_walk_shortcuts_never_change_the_image(rt, oracle, gpu, shortcuts):
     """Flat leaves for small frames, the start shortcut, instances walked last, the sequence look-ahead: every combination
-    that differs from the default (8, 1, 1, 1, 4, 32 — which every other test runs), noise-texture hits waiting in the shade stage included, renders the oracle's image bit for bit."""
+    that differs from the default (8, 1, 1, 1, 4, 32 — which every other test runs; set per scene through rt_scene_options), noise-texture hits waiting in the shade stage included, renders the oracle's image bit for bit."""
     lib = rt.amd_lib()
     cam = scene_cases.build(rt, "quads_64x64_8spp")
     scenes = [(name, scene_cases.build(rt, name)) for name in ("c1_random_balls_400x225_10spp_d10", "two_spheres_80x45_8spp", "quads_64x64_8spp",
@@ -168,12 +151,10 @@ def test_walk_shortcuts_never_change_the_image(rt, oracle, gpu, shortcuts):
     scenes += [("nested frames", custom_scenes.nested_frames_scene(cam)), ("media 1", custom_scenes.media_scene(cam, 1)),
                ("ties 2", custom_scenes.tie_scene(cam, 2))]
     params = rt.render_params(seed=3)
-    try:
-        lib.rt_debug_set_walk_shortcuts(*shortcuts)
-        for name, hs in scenes:
-            want = oracle.render(hs, params)
-            got = rt.DeviceScene(hs).render(params)
-            bad = np.flatnonzero(bits(got) != bits(want))
-            assert bad.size == 0, f"{name}, shortcuts {shortcuts}: {bad.size} of {want.size} values differ"
-    finally:
-        lib.rt_debug_set_walk_shortcuts(8, 1, 1, 1, 4, 32)
+    flat_max, start_shortcut, defer_instances, seq_lookahead, slow_min, slow_age = shortcuts
+    for name, hs in scenes:
+        want = oracle.render(hs, params)
+        got = rt.DeviceScene(hs, flat_max=flat_max, start_shortcut=start_shortcut, defer_instances=defer_instances,
+                             seq_lookahead=seq_lookahead, slow_min=slow_min, slow_age=slow_age).render(params)
+        bad = np.flatnonzero(bits(got) != bits(want))
+        assert bad.size == 0, f"{name}, shortcuts {shortcuts}: {bad.size} of {want.size} values differ"

@@ -189,7 +189,7 @@ def test_ties_depend_on_the_scan_order_in_the_oracle(rt, oracle):
 def test_small_frames_keep_their_primitives_in_one_leaf(rt):
     """Cornell box (rt_ordered.hpp flat_max): the six walls are ONE leaf under the root, beside the record holding the two
     instances; each box's six faces are one leaf under its frame's root.  4 records in all (17 with a tree per frame).
-    With the shortcut off (rt_debug_set_walk_shortcuts flat_max = 0) the trees are back."""
+    With the shortcut off (rt_scene_options.flat_max = 0) the trees are back."""
     hs = scene_cases.build(rt, "c3_cornell_box_64x64_16spp_d50")
     lay = rt.debug_ordered_layout(hs)
     assert lay["ordered"] and len(lay["nodes"]) == 4 and len(lay["quads"]) == 18 and len(lay["instances"]) == 2
@@ -203,9 +203,4 @@ def test_small_frames_keep_their_primitives_in_one_leaf(rt):
         assert kind(r[0]) == KIND_QUADS and count(r[0]) == 6 and kind(r[1]) == KIND_EMPTY
     # random-spheres (485 spheres) is a tree as before: only frames of <= 8 primitives go flat
     assert len(rt.debug_ordered_layout(scene_cases.build(rt, "c1_random_balls_400x225_10spp_d10"))["nodes"]) == 484
-    lib = rt.amd_lib()
-    try:
-        lib.rt_debug_set_walk_shortcuts(0, -1, -1, -1, -1, -1)
-        assert len(rt.debug_ordered_layout(hs)["nodes"]) == 17
-    finally:
-        lib.rt_debug_set_walk_shortcuts(8, -1, -1, -1, -1, -1)
+    assert len(rt.debug_ordered_layout(hs, flat_max=0)["nodes"]) == 17
