@@ -284,7 +284,8 @@ typedef struct rt_scene_options {
     int32_t seq_lookahead;       /* 1: scenes with media: a query that cannot reach a later step of the world's sequence ends it early */
     int32_t slow_min, slow_age;  /* hits on a noise texture wait in the shade stage for slow_min of their kind, at most slow_age shade
                                     rounds (slow_min 1: nobody waits) */
-    int32_t _reserved;
+    int32_t wide;                /* own trees: 1: records of four children, 0: of two; -1: default — four for scenes of 64 primitives or
+                                    more (DESIGN.md "Wide records") */
 } rt_scene_options;
 void rt_scene_options_init(rt_scene_options *options);
 int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_options *options /* NULL: defaults */,

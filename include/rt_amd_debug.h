@@ -84,6 +84,12 @@ int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io);
 /* ... with the tree options of `options` (leaf_max, flat_max; NULL: the process defaults) */
 int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options *options, rt_debug_ordered *io);
 
+/* Structure check of the four-child layout (rt_scene_options.wide), on the CPU: out[0] records, out[1] primitives found in leaves,
+ * out[2] primitives in the scene's tables (a medium's boundary sphere solved in place is in no leaf), out[3] stack entries a walk needs,
+ * out[4] violations (a primitive in no leaf or in two, a child record's boxes outside its slot's box, a bad reference, an empty slot
+ * whose box a ray could enter), out[5] records on the longest chain. */
+int rt_debug_wide_layout(const rt_scene_desc *desc, const rt_scene_options *options, uint64_t out[6]);
+
 /* Which kernel the calling thread's last render launched: out[0] = path slots of the pool kernel (0: path_kernel rendered —
  * also when the pool kernel was asked for and the scene did not qualify), out[1] = LDS level, out[2] = workgroup threads,
  * out[3] = workgroups. */

@@ -171,7 +171,7 @@ class SceneCreateOptions(C.Structure):
                 ("use_lds", C.c_int32), ("th_prim", C.c_int32), ("th_other", C.c_int32), ("th_shade", C.c_int32),
                 ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("pool", C.c_int32),
                 ("flat_max", C.c_int32), ("start_shortcut", C.c_int32), ("defer_instances", C.c_int32),
-                ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("_reserved", C.c_int32)]
+                ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("wide", C.c_int32)]
 
 
 def scene_options(**kw) -> "SceneCreateOptions":
@@ -238,6 +238,7 @@ RT_AMD_DEBUG_SYMBOLS = {
                                           C.POINTER(C.c_int64)]),
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
     "rt_debug_last_launch": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "rt_debug_wide_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "rt_debug_set_traversal": (C.c_int, [C.c_int32, C.c_int32]),
     "rt_debug_set_walk_shortcuts": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "rt_debug_ordered_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -305,6 +306,14 @@ def debug_ordered_layout(host_scene, **option_fields) -> dict:
     return {"ordered": bool(io.ordered), "root": int(io.root), "stack_entries": int(io.stack_entries),
             "nodes": nodes[:io.n_nodes], "spheres": spheres[:io.n_spheres], "quads": quads[:io.n_quads],
             "instances": insts[:io.n_instances], "steps": steps[:io.n_steps], "media": media[:io.n_media]}
+
+
+def debug_wide_layout(host_scene, **option_fields) -> dict:
+    """rt_debug_wide_layout: structure check of the four-child layout (CPU)."""
+    buf = (C.c_uint64 * 6)()
+    opts = scene_options(**option_fields) if option_fields else None
+    _check(amd_lib().rt_debug_wide_layout(C.addressof(host_scene.desc), C.addressof(opts) if opts is not None else None, buf), "rt_debug_wide_layout")
+    return dict(zip(("records", "found", "primitives", "stack_entries", "violations", "deepest"), (int(x) for x in buf)))
 
 
 def debug_last_launch() -> dict:

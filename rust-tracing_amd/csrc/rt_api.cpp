@@ -25,6 +25,7 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
+    env("RT_WIDE", wide);
     env("RT_POOL", pool); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
     env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
@@ -219,7 +220,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     uint32_t pool_slots = 0, pool_off = 0;
     bool pool_aux = aux_in_lds(scene, lds);
     uint32_t pool_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
-    if (!counted && tn.pool != 0 && scene->ordered && lds == 3 && p.max_depth < 65536 && tn.pool_service >= 1 && tn.pool_service * 64 < threads) {
+    if (!counted && tn.pool != 0 && scene->ordered && !scene->wide && lds == 3 && p.max_depth < 65536 && tn.pool_service >= 1 && tn.pool_service * 64 < threads) {
         // the pool takes what the scene, the stacks and the sequence leave; the small tables stay in the LDS only if the pool
         // still gets POOL_WANT_WORDS words (a pool much smaller than the number of walking lanes starves them)
         auto layout = [&](bool with_aux, uint32_t &world_off) {
@@ -451,7 +452,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
         {
             void *args[] = {(void *)&K};
             const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-            const void *fn = pooled ? pool_kernel_for(kf, pool_aux, tn.pool_prof != 0) : path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds));
+            const void *fn = pooled ? pool_kernel_for(kf, pool_aux, tn.pool_prof != 0) : path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds), scene->wide);
             if (pooled && dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, dyn_lds, s));
         }
@@ -540,7 +541,7 @@ void rt_scene_options_init(rt_scene_options *o) {
     o->th_prim = o->th_other = o->th_shade = o->th_box = o->th_new = -1;
     o->sample_buffer_bytes = 0;
     o->pool = -1;
-    o->flat_max = o->start_shortcut = o->defer_instances = o->seq_lookahead = o->slow_min = o->slow_age = -1;
+    o->flat_max = o->start_shortcut = o->defer_instances = o->seq_lookahead = o->slow_min = o->slow_age = o->wide = -1;
 }
 
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) { return rt_scene_create_ex(desc, device, nullptr, out_scene); }
@@ -563,9 +564,14 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     OrderedOptions oopt = tn.ordered_options;
     if (opt.leaf_max > 0) oopt.leaf_max = (uint32_t)opt.leaf_max < OREF_MAX_LEAF ? (uint32_t)opt.leaf_max : OREF_MAX_LEAF;
     if (opt.flat_max >= 0) oopt.flat_max = (uint32_t)opt.flat_max;
+    const bool wants_pool = opt.pool >= 0 ? opt.pool != 0 : tn.pool != 0; // (the pool kernel walks two-child records only)
+    const int want_wide = wants_pool ? 0 : (opt.wide >= 0 ? opt.wide : tn.wide); // (-1: where it measured faster, below)
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, refit);
+        // Four children per record where the trees are big enough for the halved number of visits to pay for the dearer visit
+        // (MI355X, Msamples/s two / four children: random-spheres 5428 / 5437, final_scene 1049 / 1088; Cornell's 4 records: 2438 / 2345)
+        oopt.wide = want_wide >= 0 ? want_wide != 0 : cs.spheres.size() + cs.quads.size() >= 64;
         if (walk == RT_WALK_OWN_TREES || (walk == RT_WALK_AUTO && ordered_walk_pays(cs))) build_ordered(cs, oopt);
     } catch (const CompileError &e) {
         return fail(e.status, e.what());
@@ -601,22 +607,38 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     // child; a frame of a few primitives keeps them in one leaf under its root (rt_ordered.hpp flat_max: Cornell's walls).  When the root
     // has such a child (a leaf whose box has at least half the area of the root's), a query starts in the leaf's primitive stage with the
     // other child already set aside: the same tests, minus the visit of the root record, and the lanes that start together stay together.
+    s->wide = cs.ordered && cs.wide;
     if (cs.ordered && cs.media.empty() && cs.oseq.size() == 1 && cs.oseq[0].kind == OSEQ_TREE) {
-        const ONode &root = cs.onodes[s->o_root];
         auto half_area = [](const float *b) { const double x = (double)b[1] - b[0], y = (double)b[3] - b[2], z = (double)b[5] - b[4]; return x * y + y * z + z * x; };
-        const bool empty0 = (root.c[0] >> OREF_KIND_SHIFT) == OK_EMPTY, empty1 = (root.c[1] >> OREF_KIND_SHIFT) == OK_EMPTY;
-        float all[6];
-        for (int k = 0; k < 6; k += 2) {
-            all[k] = empty1 ? root.b0[k] : (empty0 ? root.b1[k] : std::fmin(root.b0[k], root.b1[k]));
-            all[k + 1] = empty1 ? root.b0[k + 1] : (empty0 ? root.b1[k + 1] : std::fmax(root.b0[k + 1], root.b1[k + 1]));
+        // the root's children: (box, reference) in slot order — two of a binary record, up to four of a wide one
+        std::vector<std::pair<const float *, uint32_t>> kids;
+        if (s->wide) {
+            const ONode4 &root = cs.onodes4[s->o_root];
+            for (int k = 0; k < 4; ++k) kids.emplace_back(root.b[k], root.c[k]);
+        } else {
+            const ONode &root = cs.onodes[s->o_root];
+            kids.emplace_back(root.b0, root.c[0]);
+            kids.emplace_back(root.b1, root.c[1]);
         }
-        for (uint32_t slot = 0; slot < 2; ++slot) {
-            const uint32_t ref = root.c[slot], other = root.c[slot ^ 1u], kind = ref >> OREF_KIND_SHIFT;
-            if ((kind == OK_SPHERES || kind == OK_QUADS) && half_area(slot ? root.b1 : root.b0) >= 0.5 * half_area(all)) {
+        float all[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+        for (const auto &kid : kids)
+            if ((kid.second >> OREF_KIND_SHIFT) != OK_EMPTY)
+                for (int k = 0; k < 6; k += 2) { all[k] = std::fmin(all[k], kid.first[k]); all[k + 1] = std::fmax(all[k + 1], kid.first[k + 1]); }
+        for (uint32_t slot = 0; slot < kids.size(); ++slot) {
+            const uint32_t ref = kids[slot].second, kind = ref >> OREF_KIND_SHIFT;
+            if ((kind == OK_SPHERES || kind == OK_QUADS) && half_area(kids[slot].first) >= 0.5 * half_area(all)) {
                 s->o_start_stage = kind; // (OrderedKind SPHERES / QUADS = Stage ST_SPHERE / ST_QUAD)
                 s->o_start_prim = ref & OREF_INDEX_MASK;
                 s->o_start_end = s->o_start_prim + ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u;
-                s->o_start_rest = other; s->o_start_slot = slot;
+                s->o_start_slot = slot;
+                if (s->wide) { // what is set aside: the root record with the mask of its other children
+                    uint32_t mask = 0;
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (k != slot && (kids[k].second >> OREF_KIND_SHIFT) != OK_EMPTY) mask |= 1u << k;
+                    s->o_start_rest = mask;
+                } else {
+                    s->o_start_rest = kids[slot ^ 1u].second;
+                }
                 break;
             }
         }
@@ -632,13 +654,28 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     // Node tables (load_node / load_opair): threaded records as two 16-byte halves, ordered records as six 16-byte plane
     // tables and an 8-byte reference table.  LDS image = node tables | spheres | quads; every LDS level copies a prefix.
     {
-        const size_t n = cs.ordered ? cs.onodes.size() : cs.nodes32.size();
-        const size_t off_b = n * 16; // bytes of one 16-byte-per-record table
-        const size_t off_sph = cs.ordered ? ((n * (6 * 16 + 8) + 15u) & ~(size_t)15u) : n * 32;
+        const bool wide = cs.ordered && cs.wide;
+        const size_t n = wide ? cs.onodes4.size() : (cs.ordered ? cs.onodes.size() : cs.nodes32.size());
+        const size_t off_b = wide ? n * 32 : n * 16; // bytes of one plane table (16 bytes per record; wide records: 32)
+        const size_t off_sph = wide ? n * (6 * 32 + 16) : (cs.ordered ? ((n * (6 * 16 + 8) + 15u) & ~(size_t)15u) : n * 32);
         std::vector<uint4> tables(off_sph / 16);
         {
             unsigned char *base = reinterpret_cast<unsigned char *>(tables.data());
-            if (cs.ordered) {
+            if (wide) { // (rt_device_scene.h load_oquad)
+                for (size_t i = 0; i < n; ++i) {
+                    const ONode4 &nd = cs.onodes4[i];
+                    for (int ax = 0; ax < 3; ++ax) {
+                        float plus[8], minus[8];
+                        for (int k = 0; k < 4; ++k) {
+                            plus[k] = nd.b[k][2 * ax]; plus[4 + k] = nd.b[k][2 * ax + 1];   // enter through lo, leave through hi
+                            minus[k] = nd.b[k][2 * ax + 1]; minus[4 + k] = nd.b[k][2 * ax];
+                        }
+                        memcpy(base + (size_t)(2 * ax) * off_b + i * 32, plus, 32);
+                        memcpy(base + (size_t)(2 * ax + 1) * off_b + i * 32, minus, 32);
+                    }
+                    memcpy(base + 6 * off_b + i * 16, nd.c, 16);
+                }
+            } else if (cs.ordered) {
                 for (size_t i = 0; i < n; ++i) {
                     const ONode &nd = cs.onodes[i];
                     for (int ax = 0; ax < 3; ++ax) {
@@ -655,7 +692,17 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
                     for (size_t q = 0; q < 2; ++q) memcpy(base + q * off_b + i * 16, src + (i * 2 + q) * 16, 16);
             }
         }
-        if (cs.ordered) { // the global copy: one 128-byte line per record (load_opair<0>)
+        if (wide) { // the global copy: 256 bytes per record (load_oquad<0>)
+            std::vector<uint4> lines(n * 16);
+            unsigned char *dst = reinterpret_cast<unsigned char *>(lines.data());
+            const unsigned char *tab = reinterpret_cast<const unsigned char *>(tables.data());
+            for (size_t i = 0; i < n; ++i) {
+                for (size_t q = 0; q < 6; ++q) memcpy(dst + i * 256 + q * 32, tab + q * off_b + i * 32, 32);
+                memcpy(dst + i * 256 + 192, tab + 6 * off_b + i * 16, 16);
+            }
+            int urc = upload(s->oimage, lines);
+            if (urc != RT_OK) { free_scene(s); return urc; }
+        } else if (cs.ordered) { // the global copy: one 128-byte line per record (load_opair<0>)
             std::vector<uint4> lines(n * 8);
             unsigned char *dst = reinterpret_cast<unsigned char *>(lines.data());
             const unsigned char *tab = reinterpret_cast<const unsigned char *>(tables.data());
@@ -674,7 +721,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
         const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
         s->lds_level = total + stack3 <= budget ? 3 : (off_sph + stack1 <= budget ? 1 : 0);
-        if (cs.ordered && n >= 0x3fffu) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits
+        if (cs.ordered && n >= (wide ? (size_t)WIDE_MAX_LDS_RECORDS : (size_t)0x3fffu)) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits (wide: 12 + 4 mask bits)
         if (s->lds_level) {
             const size_t used = s->lds_level == 3 ? total : (s->lds_level == 2 ? ((off_quads + 15u) & ~(size_t)15u) : off_sph);
             std::vector<uint4> img(used / 16);
@@ -743,7 +790,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     for (int lds = 0; lds < 4; ++lds)
         for (int counted = 0; counted < 2; ++counted) {
             if (lds && lds != s->lds_level) { s->blocks_per_cu[lds][counted] = 0; continue; }
-            const void *fn = path_kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered, aux_in_lds(s, lds));
+            const void *fn = path_kernel_for(lds, counted != 0, kernel_features_for(s->features, lds, s->ordered), s->ordered, aux_in_lds(s, lds), s->wide);
             const int threads = block_threads(s, lds);
             const size_t dyn = dynamic_lds_bytes(s, lds, counted != 0);
             if (dyn > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
@@ -768,7 +815,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     st.node_bytes = cs.ordered ? s->oimage.bytes : s->nodes.bytes; st.sphere_bytes = s->spheres.bytes; st.quad_bytes = s->quads.bytes;
     st.instance_bytes = s->insts.bytes; st.medium_bytes = s->media.bytes; st.material_bytes = s->mats.bytes;
     st.texture_bytes = s->texs.bytes; st.perlin_bytes = s->perlins.bytes; st.image_bytes = s->texels.bytes;
-    st.n_nodes = (uint32_t)(cs.ordered ? cs.onodes.size() : cs.nodes.size()); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
+    st.n_nodes = (uint32_t)(cs.ordered ? (cs.wide ? cs.onodes4.size() : cs.onodes.size()) : cs.nodes.size()); st.n_spheres = (uint32_t)cs.spheres.size(); st.n_quads = (uint32_t)cs.quads.size();
     st.n_instances = (uint32_t)cs.instances.size(); st.n_media = (uint32_t)cs.media.size();
     st.max_instance_depth = cs.max_instance_depth;
     st.lds_nodes = s->lds_level ? st.n_nodes : 0; st.lds_bytes = s->lds_level ? (uint32_t)dynamic_lds_bytes(s, s->lds_level, false) : 0;

@@ -71,6 +71,7 @@ struct Tuning {
     int ordered = 1; // scenes created from now on: 0 always the reference-order walk, 1 the ordered walk where it pays
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
+    int wide = -1;         // own trees with four-child records (rt_layout.h ONode4): 1 always, 0 never, -1 for scenes of 64 primitives or more (RT_WIDE)
     int pool = 0;          // 1: ordered LDS-resident scenes render with the pool kernel (ray compaction across stages; RT_POOL)
     int pool_prof = 0;     // ... 1: the instrumented variant; prints a per-section cycle profile to stderr after every render (RT_POOL_PROF)
     int pool_aux = -1, pool_want_words = 8; // ... small tables in the LDS too: 1 yes, 0 no, -1 only if the pool still gets this many words
@@ -134,6 +135,7 @@ struct rt_scene {
     rtapi::DeviceArray<double> lut;
     uint32_t n_nodes = 0;
     bool ordered = false;                        // ordered layout (rt_ordered.hpp): onodes instead of nodes
+    bool wide = false;                           // ... with four-child records (onodes4)
     rtapi::DeviceArray<uint4> oimage;                   // ordered layout: the tables of load_opair (global copy)
     rtapi::DeviceArray<OSeq> oseq;                      // ... and the world frame's sequence
     uint32_t n_oseq = 0;

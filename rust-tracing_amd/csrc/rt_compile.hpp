@@ -90,6 +90,8 @@ struct CompiledScene {
     // ordered layout (rt_ordered.hpp), when the scene allows it: the primitive tables are then in leaf order
     bool ordered = false;
     std::vector<ONode> onodes;
+    bool wide = false;           // ... walked through the four-child records below instead (rt_layout.h ONode4)
+    std::vector<ONode4> onodes4;
     std::vector<OSeq> oseq;     // the world frame's sequence of trees and media
     uint32_t ordered_stack = 0; // stack entries a lane needs at most
     std::vector<Sphere> spheres;

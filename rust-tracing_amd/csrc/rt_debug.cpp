@@ -111,6 +111,76 @@ int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options
     return RT_OK;
 }
 
+// Structure check of the wide layout (no device): walks every tree from its root and reports
+//   out[0] records, out[1] primitives found in leaves, out[2] primitives of the scene's tables, out[3] stack entries a walk needs,
+//   out[4] violations (a primitive in no leaf or in two, a child's box not inside its parent's slot, a reference out of range),
+//   out[5] deepest chain of records
+int rt_debug_wide_layout(const rt_scene_desc *desc, const rt_scene_options *options, uint64_t out[6]) {
+    if (!desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wide_layout: null argument");
+    CompiledScene cs;
+    try {
+        cs = compile_scene(*desc, true);
+        OrderedOptions oopt = tuning_snapshot().ordered_options;
+        if (options && options->struct_size >= sizeof(rt_scene_options)) {
+            if (options->leaf_max > 0) oopt.leaf_max = (uint32_t)options->leaf_max < OREF_MAX_LEAF ? (uint32_t)options->leaf_max : OREF_MAX_LEAF;
+            if (options->flat_max >= 0) oopt.flat_max = (uint32_t)options->flat_max;
+        }
+        oopt.wide = true;
+        build_ordered(cs, oopt);
+    } catch (const CompileError &e) {
+        return fail(e.status, e.what());
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("rt_debug_wide_layout: ") + e.what());
+    }
+    for (int k = 0; k < 6; ++k) out[k] = 0;
+    if (!cs.ordered || !cs.wide) return RT_OK;
+    std::vector<uint32_t> seen_s(cs.spheres.size(), 0), seen_q(cs.quads.size(), 0), seen_r(cs.onodes4.size(), 0);
+    uint64_t violations = 0, deepest = 0;
+    struct Walk { uint32_t rec; uint64_t depth; };
+    std::vector<Walk> todo;
+    for (const OSeq &st : cs.oseq) {
+        if (st.kind == OSEQ_TREE) todo.push_back({st.a, 1});
+        else if (st.kind == OSEQ_MEDIUM) todo.push_back({st.b, 1});
+    }
+    for (const Instance &in : cs.instances) todo.push_back({in.root, 1});
+    while (!todo.empty()) {
+        const Walk w = todo.back();
+        todo.pop_back();
+        if (w.rec >= cs.onodes4.size()) { violations++; continue; }
+        if (seen_r[w.rec]++) continue; // (an instance's root is reached from the table above and, as a child, never: each record once)
+        deepest = std::max(deepest, w.depth);
+        const ONode4 &nd = cs.onodes4[w.rec];
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t kind = nd.c[k] >> OREF_KIND_SHIFT, index = nd.c[k] & OREF_INDEX_MASK, count = ((nd.c[k] >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u;
+            if (kind == OK_EMPTY) { if (!(nd.b[k][0] > nd.b[k][1])) violations++; continue; } // an empty slot's box must admit no ray
+            if (kind == OK_INNER) {
+                if (index >= cs.onodes4.size()) { violations++; continue; }
+                const ONode4 &ch = cs.onodes4[index];
+                for (int q = 0; q < 4; ++q)
+                    if ((ch.c[q] >> OREF_KIND_SHIFT) != OK_EMPTY)
+                        for (int ax = 0; ax < 3; ++ax)
+                            if (ch.b[q][2 * ax] < nd.b[k][2 * ax] || ch.b[q][2 * ax + 1] > nd.b[k][2 * ax + 1]) violations++;
+                todo.push_back({index, w.depth + 1});
+            } else if (kind == OK_SPHERES) {
+                for (uint32_t i = 0; i < count; ++i) { if (index + i >= seen_s.size()) violations++; else seen_s[index + i]++; }
+            } else if (kind == OK_QUADS) {
+                for (uint32_t i = 0; i < count; ++i) { if (index + i >= seen_q.size()) violations++; else seen_q[index + i]++; }
+            } else if (kind == OK_INSTANCE) {
+                if (index >= cs.instances.size()) violations++;
+            } else violations++;
+        }
+    }
+    uint64_t found = 0;
+    // (the boundary spheres of media solved in place are in no leaf: they sit behind the leaves' spheres, cs.media[].first_node)
+    std::vector<bool> boundary(cs.spheres.size(), false);
+    for (const OSeq &st : cs.oseq)
+        if (st.kind == OSEQ_MEDIUM_SPHERE) boundary[cs.media[st.a].first_node] = true;
+    for (size_t i = 0; i < seen_s.size(); ++i) { found += seen_s[i]; if (seen_s[i] != (boundary[i] ? 0u : 1u)) violations++; }
+    for (size_t i = 0; i < seen_q.size(); ++i) { found += seen_q[i]; if (seen_q[i] != 1u) violations++; }
+    out[0] = cs.onodes4.size(); out[1] = found; out[2] = cs.spheres.size() + cs.quads.size(); out[3] = cs.ordered_stack; out[4] = violations; out[5] = deepest;
+    return RT_OK;
+}
+
 int rt_debug_compiled_nodes(const rt_scene_desc *desc, int32_t refit, rt_debug_node *out_nodes, int64_t capacity, int64_t *out_count) {
     if (!desc || !out_count) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_compiled_nodes: null argument");
     CompiledScene cs;

@@ -295,7 +295,8 @@ RT_DEV RayPair32 make_ray_pair32(V3 o, V3 d, uint32_t table_bytes, float extent)
     r.offy = (iy < 0.0f ? 3u : 2u) * table_bytes;
     r.offz = (iz < 0.0f ? 5u : 4u) * table_bytes;
     const float fsum = (ex + ey + ez) + (__builtin_fabsf(ix) + __builtin_fabsf(iy) + __builtin_fabsf(iz));
-    r.degenerate = !(fsum < __builtin_inff()); // an inf or a NaN anywhere: every box is entered
+    // an inf or a NaN anywhere, or a zero 1/d (an infinite direction component: plane * 0 is a NaN for an infinite plane): every box is entered
+    r.degenerate = !(fsum < __builtin_inff()) || ix == 0.0f || iy == 0.0f || iz == 0.0f;
     return r;
 }
 // planes * (the chosen half of inv, for both boxes) + (the chosen half of off, for both boxes)
@@ -330,6 +331,62 @@ RT_DEV void box_pair_f32(const OPair &b, const RayPair32 &r, float tmin32, float
     miss1 = !r.degenerate && en1 > le1;
     enter0 = en0;
     enter1 = en1;
+}
+// ---- wide records (rt_layout.h ONode4): four children per record -------------------------------------------------------------
+// Tables as for the pairs, 32 bytes per record each: X+ | X- | Y+ | Y- | Z+ | Z-  = (near planes of children 0..3, far planes of
+// children 0..3) for a ray of that sign on that axis; then R, 16 bytes: the four references.  In global memory the seven pieces of a
+// record sit side by side in 256 bytes (offsets 0 .. 160, 192).
+struct OQuad {
+    f32x2 nx[2], fx[2], ny[2], fy[2], nz[2], fz[2]; // [0]: children 0, 1; [1]: children 2, 3
+    uint32_t c[4];
+};
+template <int LDS> RT_DEV OQuad load_oquad(const KParams &P, const unsigned char *lds, uint32_t id, uint32_t offx, uint32_t offy, uint32_t offz) {
+    float4 q[6];
+    uint4 r;
+    if constexpr (LDS != 0) {
+        const unsigned char *bx = lds + offx + id * 32u, *by = lds + offy + id * 32u, *bz = lds + offz + id * 32u;
+        q[0] = *reinterpret_cast<const float4 *>(bx); q[1] = *reinterpret_cast<const float4 *>(bx + 16);
+        q[2] = *reinterpret_cast<const float4 *>(by); q[3] = *reinterpret_cast<const float4 *>(by + 16);
+        q[4] = *reinterpret_cast<const float4 *>(bz); q[5] = *reinterpret_cast<const float4 *>(bz + 16);
+        r = *reinterpret_cast<const uint4 *>(lds + 6u * P.lds_off_node_b + id * 16u);
+    } else {
+        const unsigned char *rec = reinterpret_cast<const unsigned char *>(P.oimage) + (size_t)id * 256u;
+        q[0] = *reinterpret_cast<const float4 *>(rec + offx); q[1] = *reinterpret_cast<const float4 *>(rec + offx + 16);
+        q[2] = *reinterpret_cast<const float4 *>(rec + offy); q[3] = *reinterpret_cast<const float4 *>(rec + offy + 16);
+        q[4] = *reinterpret_cast<const float4 *>(rec + offz); q[5] = *reinterpret_cast<const float4 *>(rec + offz + 16);
+        r = *reinterpret_cast<const uint4 *>(rec + 192);
+    }
+    OQuad n;
+    n.nx[0] = f32x2{q[0].x, q[0].y}; n.nx[1] = f32x2{q[0].z, q[0].w}; n.fx[0] = f32x2{q[1].x, q[1].y}; n.fx[1] = f32x2{q[1].z, q[1].w};
+    n.ny[0] = f32x2{q[2].x, q[2].y}; n.ny[1] = f32x2{q[2].z, q[2].w}; n.fy[0] = f32x2{q[3].x, q[3].y}; n.fy[1] = f32x2{q[3].z, q[3].w};
+    n.nz[0] = f32x2{q[4].x, q[4].y}; n.nz[1] = f32x2{q[4].z, q[4].w}; n.fz[0] = f32x2{q[5].x, q[5].y}; n.fz[1] = f32x2{q[5].z, q[5].w};
+    n.c[0] = r.x; n.c[1] = r.y; n.c[2] = r.z; n.c[3] = r.w;
+    return n;
+}
+// the conservative test of box_pair_f32 for the four boxes of a record: where the ray enters each (clamped to the interval's start)
+// and leaves it (clamped to its end); the ray misses box k iff enter[k] > leave[k]
+RT_DEV void box_quad_f32(const OQuad &b, const RayPair32 &r, float tmin32, float tmax32, float enter[4], float leave[4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x2 tnx, tny, tnz, tfx, tfy, tfz;
+        RT_PK_FMA_SEL(tnx, b.nx[h], r.ixy, r.nxy, RT_SEL_LO_LO);
+        RT_PK_FMA_SEL(tny, b.ny[h], r.ixy, r.nxy, RT_SEL_HI_HI);
+        RT_PK_FMA_SEL(tnz, b.nz[h], r.izs, r.nfz, RT_SEL_LO_LO);
+        RT_PK_FMA_SEL(tfx, b.fx[h], r.ixy, r.fxy, RT_SEL_LO_LO);
+        RT_PK_FMA_SEL(tfy, b.fy[h], r.ixy, r.fxy, RT_SEL_HI_HI);
+        RT_PK_FMA_SEL(tfz, b.fz[h], r.izs, r.nfz, RT_SEL_LO_HI);
+        float en0, en1, le0, le1;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(en0) : "v"(tnx.x), "v"(tny.x), "v"(tnz.x));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(en1) : "v"(tnx.y), "v"(tny.y), "v"(tnz.y));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(le0) : "v"(tfx.x), "v"(tfy.x), "v"(tfz.x));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(le1) : "v"(tfx.y), "v"(tfy.y), "v"(tfz.y));
+        asm("v_max_f32 %0, %1, %2" : "=v"(en0) : "v"(en0), "v"(tmin32));
+        asm("v_max_f32 %0, %1, %2" : "=v"(en1) : "v"(en1), "v"(tmin32));
+        asm("v_min_f32 %0, %1, %2" : "=v"(le0) : "v"(le0), "v"(tmax32));
+        asm("v_min_f32 %0, %1, %2" : "=v"(le1) : "v"(le1), "v"(tmax32));
+        enter[2 * h] = en0; enter[2 * h + 1] = en1;
+        leave[2 * h] = le0; leave[2 * h + 1] = le1;
+    }
 }
 // one box given as (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi) in both slots of a pair, as the "+" / "-" tables would hold it
 RT_DEV OPair opair_of_box(const float b[6], const RayPair32 &r) {

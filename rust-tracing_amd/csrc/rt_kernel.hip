@@ -50,7 +50,8 @@ enum Terminal : uint32_t { TERM_BACKGROUND = 0, TERM_ONE = 1, TERM_ZERO = 2, TER
 // records in the reference's order
 // AUX: the small tables (materials, textures, frames, media, Perlin) are copied into the LDS too — for scenes whose big
 // tables do not fit there, so that a hit's material -> texture -> noise chain is not three trips to memory
-template <bool COUNT, int LDS, int THREADS, uint32_t FEAT, bool ORDERED, bool AUX = false>
+// WIDE: the ordered walk's records hold four children (rt_layout.h ONode4) instead of two
+template <bool COUNT, int LDS, int THREADS, uint32_t FEAT, bool ORDERED, bool AUX = false, bool WIDE = false>
 __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(const KParams P) {
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
                    HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // f32 copies for the conservative box test: origin, 1/d, and the bound E on what rounding the origin to f32
     // can move a slab distance (see the box stage); `degenerate`: some 1/d or E is not finite -> enter every box
     std::conditional_t<ORDERED, RayPair32, Ray32> r32;
-    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : 16u, P.box_extent); else r32 = make_ray32(o, d);
+    if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : (WIDE ? 32u : 16u), P.box_extent); else r32 = make_ray32(o, d);
     float tmin32 = 0, tmax32 = 0;
     uint32_t job = 0;
     int32_t depth = 0;
@@ -145,11 +146,14 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     constexpr uint32_t S_EXIT = LDS != 0 ? 0xffffu : 0xffffffffu;
     constexpr uint32_t SKIP_CHILD0 = LDS != 0 ? 0x4000u : 0x40000000u, SKIP_CHILD1 = LDS != 0 ? 0x8000u : 0x80000000u,
                        NODE_INDEX = SKIP_CHILD0 - 1u;
+    // wide records: an entry is a record's index and, above it, the mask of its children still to look at (all four for a record
+    // the walk comes to for the first time)
+    constexpr uint32_t W_SHIFT = LDS != 0 ? 12u : 26u, W_INDEX = (1u << W_SHIFT) - 1u, W_FULL = WIDE ? (0xfu << W_SHIFT) : 0u;
     constexpr uint32_t NODE_FRAME_EXIT = 0xffffffffu, NODE_SEQ_NEXT = 0xfffffffeu; // ST_OTHER: leave the current frame / take the next step of the world's sequence
     StackT *const stack = reinterpret_cast<StackT *>(lds_raw + P.lds_stack_off) + threadIdx.x;
     uint32_t sp = 0;
     uint32_t seq_pc = 0; // (scenes with media) the next step of the world frame's sequence
-    const uint32_t first_node = ORDERED ? P.o_root : 0u;
+    const uint32_t first_node = ORDERED ? (P.o_root == 0xfffffffeu ? P.o_root : (P.o_root | W_FULL)) : 0u;
     // what a lane does next in an ordered walk: go to `ref` if it has one, else take the last child set aside
     // (written as selects of VALUES: when the branches assign different variables the optimiser turns them into one store
     // through a selected address, and the variables end up in scratch memory — in the hottest loop of the kernel)
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             const uint32_t kind = ref >> OREF_KIND_SHIFT, index = ref & OREF_INDEX_MASK;
             const bool leaf = kind == OK_SPHERES || kind == OK_QUADS;
             new_stage = kind;
-            new_node = leaf ? node : index;
+            new_node = leaf ? node : (kind == OK_INNER ? (index | W_FULL) : index); // (an inner record is come to with all four children to look at)
             new_cur = leaf ? index : prim_cur;
             new_end = leaf ? index + ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u : prim_end;
         } else if (sp != 0) { // the last child set aside
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     const uint32_t n_nodes = P.n_nodes;
 
     auto refresh_ray32 = [&]() {
-        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : 16u, P.box_extent);
+        if constexpr (ORDERED) r32 = make_ray_pair32(o, d, LDS != 0 ? P.lds_off_node_b : (WIDE ? 32u : 16u), P.box_extent);
         else r32 = make_ray32(o, d);
     };
     // (the ordered walk's test takes the interval rounded outward; the threaded one has the slack for either rounding)
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 box_pair_f32(opair_of_box(rec->box, r32), r32, __double2float_rd(cur_tmin), __double2float_ru(cur_tmax), miss0, miss1, enter, enter);
                 if (miss0) continue;
                 if (rec->kind == OSEQ_TREE) {
-                    node = rec->a; sp = 0; stage = ST_BOX;
+                    node = rec->a | W_FULL; sp = 0; stage = ST_BOX;
                 } else if (rec->kind == OSEQ_MEDIUM_SPHERE) {
                     medium_sphere_hit(rec->a, ld3(rec->center), ld3(rec->center_vec), rec->moving != 0, rec->radius, rec->neg_inv_density);
                     // (it may have lowered cur_tmax: the following steps are tested against that)
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     mode = 1;
                     cur_tmin = -INF;
                     cur_tmax = INF;
-                    node = rec->b; sp = 0; stage = ST_BOX;
+                    node = rec->b | W_FULL; sp = 0; stage = ST_BOX;
                 }
                 break;
             }
@@ -399,6 +403,68 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 sp++;
             }
             o_next(h0 || h1, one_first ? nd.c1 : nd.c0);
+        }
+    };
+    // ---- one WIDE record (rt_layout.h ONode4): four boxes at once, on with the nearest child that is hit; if others are hit too the
+    // record itself is set aside with the mask of those — they are looked at again when its turn comes, against the interval as it has
+    // shrunk by then (a child missed now is missed then: it leaves the mask for good)
+    auto visit_wide = [&]() {
+        if constexpr (ORDERED && WIDE) {
+            const uint32_t nid = node & W_INDEX;
+            const uint32_t todo = (node >> W_SHIFT) & 0xfu;
+            const OQuad nd = load_oquad<LDS>(P, lds_raw, nid, r32.offx, r32.offy, r32.offz);
+            if (COUNT) cn.node_visits++;
+            float en[4], le[4];
+            box_quad_f32(nd, r32, tmin32, tmax32, en, le);
+            // Which children are entered, and which of them first — in integer arithmetic on the floats' bits (a compare-and-select per
+            // child costs two instructions and the wait states between them; these cost one each).  A box is missed iff leave - enter is
+            // negative (no NaN can arise here: planes and ray constants are finite, an empty slot gives -inf); the sign, spread over the
+            // word, turns the child's key — where the ray enters it — into an all-ones NaN, which the minimum ignores and nothing equals;
+            // so does the complement of the entry's mask for a child that is no longer to be looked at.
+            uint32_t missed[4], key[4];
+            uint32_t miss_bits = 0;
+        #pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                missed[k] = (uint32_t)((int32_t)__float_as_uint(le[k] - en[k]) >> 31);
+                miss_bits |= missed[k] & (1u << k);
+                key[k] = __float_as_uint(en[k]) | missed[k] | (uint32_t)((int32_t)(~todo << (31u - k)) >> 31);
+            }
+            uint32_t hit = ~miss_bits & todo;
+            if (__ballot(r32.degenerate) != 0ull) { // a ray with a zero or infinite direction component: every box that exists is entered
+                if (r32.degenerate) {
+                    hit = 0;
+        #pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) hit |= nd.c[k] < (OK_EMPTY << OREF_KIND_SHIFT) ? (1u << k) : 0u;
+                    hit &= todo;
+        #pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) key[k] = (hit >> k & 1u) ? 0u : 0xffffffffu; // (in any order)
+                }
+            }
+            if constexpr (DEFER) {
+                // the world frame's instances are noted, not entered (see `deferred`); rare, so behind a wave-uniform branch
+                const uint32_t c01 = nd.c[0] > nd.c[1] ? nd.c[0] : nd.c[1], c23 = nd.c[2] > nd.c[3] ? nd.c[2] : nd.c[3];
+                if (defer && __ballot((c01 > c23 ? c01 : c23) >= (OK_INSTANCE << OREF_KIND_SHIFT)) != 0ull) {
+                    if (cur_inst < 0) {
+        #pragma unroll
+                        for (uint32_t k = 0; k < 4u; ++k)
+                            if ((hit >> k & 1u) && (nd.c[k] >> OREF_KIND_SHIFT) == OK_INSTANCE) { deferred |= 1u << (nd.c[k] & 31u); hit &= ~(1u << k); key[k] = 0xffffffffu; }
+                    }
+                }
+            }
+            // the nearest of the children that are entered (v_min3 / v_min return the operand that is not a NaN)
+            float m012, nearest;
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m012) : "v"(__uint_as_float(key[0])), "v"(__uint_as_float(key[1])), "v"(__uint_as_float(key[2])));
+            asm("v_min_f32 %0, %1, %2" : "=v"(nearest) : "v"(m012), "v"(__uint_as_float(key[3])));
+            uint32_t t = 3u, ref = nd.c[3];
+            if (__uint_as_float(key[2]) == nearest) { t = 2u; ref = nd.c[2]; }
+            if (__uint_as_float(key[1]) == nearest) { t = 1u; ref = nd.c[1]; }
+            if (__uint_as_float(key[0]) == nearest) { t = 0u; ref = nd.c[0]; }
+            const uint32_t rest = hit & ~(1u << t);
+            if (rest != 0u) {
+                stack[sp * THREADS] = (StackT)(nid | (rest << W_SHIFT));
+                sp++;
+            }
+            o_next(hit != 0u, ref);
         }
     };
     // COUNT only: per stage, rounds run / lanes active in them / shader cycles spent (wave-level, kept by lane 0)
@@ -484,7 +550,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             uint32_t in_box;
             do {
                 if constexpr (ORDERED) {
-                    if (stage == ST_BOX) visit_record();
+                    if (stage == ST_BOX) { if constexpr (WIDE) visit_wide(); else visit_record(); }
                 } else {
                     if (stage == ST_BOX) {
                         const NodeData nd = load_node<LDS>(P, lds_raw, node);
@@ -588,7 +654,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if ((mode & 3u) != 0) { // a boundary query of the medium at the previous step
                         const OSeq *rec = &seq_tab[seq_pc - 1u];
                         again = medium_boundary_done(rec->a, rec->neg_inv_density);
-                        if (again) { node = rec->b; sp = 0; stage = ST_BOX; }
+                        if (again) { node = rec->b | W_FULL; sp = 0; stage = ST_BOX; }
                     }
                     if (!again) seq_advance();
                     refresh_interval32();
@@ -615,7 +681,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     refresh_ray32();
                     a = len2(d);
                     if (leaving) o_next(false, 0u);
-                    else { node = inst_tab[cur_inst].root; stage = ST_BOX; }
+                    else { node = inst_tab[cur_inst].root | W_FULL; stage = ST_BOX; }
                 }
             } else
             if (stage == ST_OTHER) {
@@ -953,8 +1019,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 // —, and a round costs the same for 23 lanes as for 43: the 1.2 tests per sample spent on rays that miss the leaf's box are free.)
                 if (P.o_start_stage != 0u) { // the root's big leaf first, its other child set aside (rt_api.cpp "start shortcut")
                     const uint32_t rest = P.o_start_rest;
-                    if ((rest >> OREF_KIND_SHIFT) != OK_EMPTY) {
-                        stack[0] = (StackT)(rest < (1u << OREF_KIND_SHIFT) ? rest : (first_node | (P.o_start_slot ? SKIP_CHILD1 : SKIP_CHILD0)));
+                    if (WIDE ? rest != 0u : (rest >> OREF_KIND_SHIFT) != OK_EMPTY) {
+                        if constexpr (WIDE) stack[0] = (StackT)((first_node & W_INDEX) | (rest << W_SHIFT)); // (rest: the mask of the root's other children)
+                        else stack[0] = (StackT)(rest < (1u << OREF_KIND_SHIFT) ? rest : (first_node | (P.o_start_slot ? SKIP_CHILD1 : SKIP_CHILD0)));
                         sp = 1;
                     }
                     prim_cur = P.o_start_prim;
@@ -1127,9 +1194,10 @@ int kernel_threads_for(uint32_t kernel_features, int lds) {
     if (kernel_features == FEAT_QUADS_FRAMES) return QUADS_FRAMES_THREADS;
     return kernel_features == FEAT_SPHERES_SOLID ? LDS_THREADS : LDS_THREADS_GENERAL;
 }
-const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux) {
+const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux, bool wide) {
 #define RT_PICK(L, T, F, O, A) (counted ? (const void *)path_kernel<true, L, T, F, O, A> : (const void *)path_kernel<false, L, T, F, O, A>)
-#define RT_PICK_AUX(L, T, F) (aux ? RT_PICK(L, T, F, true, true) : RT_PICK(L, T, F, true, false))
+#define RT_PICK_W(L, T, F, A) (counted ? (const void *)path_kernel<true, L, T, F, true, A, true> : (const void *)path_kernel<false, L, T, F, true, A, true>)
+#define RT_PICK_AUX(L, T, F) (wide ? (aux ? RT_PICK_W(L, T, F, true) : RT_PICK_W(L, T, F, false)) : (aux ? RT_PICK(L, T, F, true, true) : RT_PICK(L, T, F, true, false)))
     if (ordered) { // (AUX: the small tables in the LDS as well, wherever they fit — rt_api.cpp decides)
         if (lds == 3) {
             if (feat == FEAT_SPHERES_SOLID) return RT_PICK_AUX(3, LDS_THREADS, FEAT_SPHERES_SOLID);
@@ -1152,6 +1220,7 @@ const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, 
     if (lds == 1) return RT_PICK(1, LDS_THREADS_GENERAL, F_ALL, false, false);
     return RT_PICK(0, GLOBAL_THREADS, F_ALL, false, false);
 #undef RT_PICK_AUX
+#undef RT_PICK_W
 #undef RT_PICK
 }
 

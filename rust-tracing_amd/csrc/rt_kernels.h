@@ -134,7 +134,7 @@ constexpr uint32_t FEAT_QUADS_FRAMES_MEDIA = F_QUADS | F_FRAMES | F_MEDIA;      
 constexpr uint32_t FEAT_SPHERES_QUADS_TEXTURES = F_SPHERES | F_QUADS | F_TEXTURES;    // two_spheres, earth, two_perlin_spheres, simple_light
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
 int kernel_threads_for(uint32_t kernel_features, int lds); // workgroup size of that instantiation
-const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux);
+const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux, bool wide);
 const void *pool_kernel_for(uint32_t feat, bool aux, bool prof); // ordered, LDS-resident scenes (lds level 3)
 size_t pool_ctl_bytes();
 constexpr size_t POOL_SLOT_BYTES = 96;

@@ -66,6 +66,17 @@ struct alignas(64) ONode {
     uint32_t _pad[2];
 };
 static_assert(sizeof(ONode) == 64, "ONode must be 64 bytes");
+// Wide records (rt_scene_options.wide): one record = up to FOUR children, made by pulling the grandchildren of a binary record up
+// (rt_ordered.hpp widen).  A walk enters the nearest child whose box it hits and sets the RECORD aside with a mask of the children
+// still to look at; when the entry's turn comes the record's boxes are tested again, against the interval as it has shrunk by then.
+// An unused slot holds an empty reference and a box no ray enters (lo = +inf, hi = -inf).
+struct alignas(128) ONode4 {
+    float b[4][6]; // child k: x.lo, x.hi, y.lo, y.hi, z.lo, z.hi (f32, rounded outward)
+    uint32_t c[4]; // as ONode::c
+    uint32_t _pad[4];
+};
+static_assert(sizeof(ONode4) == 128, "ONode4 must be 128 bytes");
+constexpr uint32_t WIDE_MAX_LDS_RECORDS = 4094; // 2-byte stack entries of the LDS kernels: 12 bits of record index + 4 bits of child mask
 constexpr uint32_t ORDERED_MAX_STACK = 32; // per-lane stack entries the kernel provides at most
 // The world frame of an ordered scene is a sequence of these, walked in order (rt_ordered.hpp): a tree over a run of
 // medium-free objects, or a ConstantMedium — bounded by one Sphere (solved in place) or by a subtree with its own tree.

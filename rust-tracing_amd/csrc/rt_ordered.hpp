@@ -18,6 +18,7 @@
 #pragma once
 #include "rt_compile.hpp"
 #include <algorithm>
+#include <cstring>
 #include <numeric>
 
 namespace rtd {
@@ -33,6 +34,7 @@ struct OrderedOptions {
                                   // under its root, beside the tree of its instances: the lanes that enter the frame test them together (0: off)
     uint32_t frame_slack = 4;     // ... and at most this many more than an even split of the tree's items needs
                                   // (the kernel's stack holds ORDERED_MAX_STACK entries in all, frames below included)
+    bool wide = false;            // four-child records (rt_layout.h ONode4): every binary record's grandchildren pulled up
 };
 
 class OrderedBuilder {
@@ -108,10 +110,11 @@ class OrderedBuilder {
         }
         // (nothing of cs_ has been touched up to here: a scene that is turned down keeps its threaded layout intact)
         if (need > ORDERED_MAX_STACK || seq.size() > ORDERED_MAX_STEPS) return false;
-        if (seq.empty()) { // nothing can be hit: one tree whose root has two empty children
+        if (seq.empty()) { // nothing can be hit: one tree whose root has only empty children
             OSeq o{};
             o.kind = OSEQ_TREE;
             o.a = alloc_node();
+            if (opt_.wide) o.a = widen(o.a).ref;
             seq.push_back(o);
         }
         for (size_t i = 0; i < cs_.instances.size(); ++i) cs_.instances[i].root = root_[frame_of_inst_[i]];
@@ -119,6 +122,8 @@ class OrderedBuilder {
         cs_.spheres.swap(new_spheres_);
         cs_.quads.swap(new_quads_);
         cs_.onodes.swap(nodes_);
+        cs_.onodes4.swap(wnodes_);
+        cs_.wide = opt_.wide;
         cs_.oseq.swap(seq);
         cs_.ordered_stack = need;
         cs_.ordered = true;
@@ -145,6 +150,7 @@ class OrderedBuilder {
     std::vector<uint32_t> need_, root_;
     std::vector<Bound> bound_;
     std::vector<ONode> nodes_;
+    std::vector<ONode4> wnodes_;
     std::vector<Sphere> new_spheres_;
     std::vector<Quad> new_quads_;
 
@@ -249,7 +255,73 @@ class OrderedBuilder {
         n.c[slot] = c.ref;
     }
 
+    // ---- four-child records: the binary tree of frame f, collapsed ------------------------------------------------------------
+    // A record's children are the binary record's two; as long as there is room, the inner child with the largest box is replaced
+    // by its own two children.  The mask scheme of the walk (rt_layout.h) keeps ONE stack entry per record on the path, so a walk
+    // below a record needs 1 + the deepest child's entries.
+    struct Wide { uint32_t ref; uint32_t need; };
+    Wide widen(uint32_t bin_id) {
+        struct Child { float b[6]; uint32_t ref; };
+        std::vector<Child> ch;
+        auto add_children_of = [&](uint32_t id) {
+            const ONode &n = nodes_[id];
+            for (int k = 0; k < 2; ++k)
+                if ((n.c[k] >> OREF_KIND_SHIFT) != OK_EMPTY) {
+                    Child c;
+                    memcpy(c.b, k ? n.b1 : n.b0, sizeof c.b);
+                    c.ref = n.c[k];
+                    ch.push_back(c);
+                }
+        };
+        add_children_of(bin_id);
+        auto area = [](const float *b) { const double x = (double)b[1] - b[0], y = (double)b[3] - b[2], z = (double)b[5] - b[4]; return x * y + y * z + z * x; };
+        for (;;) {
+            int best = -1;
+            for (size_t i = 0; i < ch.size(); ++i)
+                if ((ch[i].ref >> OREF_KIND_SHIFT) == OK_INNER) {
+                    const ONode &n = nodes_[ch[i].ref];
+                    const size_t grand = ((n.c[0] >> OREF_KIND_SHIFT) != OK_EMPTY) + ((n.c[1] >> OREF_KIND_SHIFT) != OK_EMPTY);
+                    if (ch.size() - 1 + grand <= 4 && (best < 0 || area(ch[i].b) > area(ch[(size_t)best].b))) best = (int)i;
+                }
+            if (best < 0) break;
+            const uint32_t id = ch[(size_t)best].ref;
+            ch.erase(ch.begin() + best);
+            add_children_of(id);
+        }
+        const uint32_t wid = (uint32_t)wnodes_.size();
+        wnodes_.emplace_back();
+        uint32_t need = 0;
+        ONode4 rec{};
+        for (int k = 0; k < 4; ++k) {
+            rec.c[k] = OK_EMPTY << OREF_KIND_SHIFT;
+            for (int ax = 0; ax < 3; ++ax) { rec.b[k][2 * ax] = INFINITY; rec.b[k][2 * ax + 1] = -INFINITY; }
+        }
+        for (size_t i = 0; i < ch.size(); ++i) {
+            memcpy(rec.b[i], ch[i].b, sizeof ch[i].b);
+            const uint32_t kind = ch[i].ref >> OREF_KIND_SHIFT;
+            if (kind == OK_INNER) {
+                const Wide w = widen(ch[i].ref);
+                rec.c[i] = w.ref;
+                need = std::max(need, w.need);
+            } else {
+                rec.c[i] = ch[i].ref;
+                if (kind == OK_INSTANCE) need = std::max(need, 1u + need_[frame_of_inst_[ch[i].ref & OREF_INDEX_MASK]]); // exit marker + the walk inside
+            }
+        }
+        wnodes_[wid] = rec;
+        return Wide{wid, 1u + need};
+    }
+
     void build_frame(size_t f) {
+        build_binary_frame(f);
+        if (opt_.wide && need_[f] <= ORDERED_MAX_STACK) {
+            const Wide w = widen(root_[f]);
+            root_[f] = w.ref;
+            need_[f] = w.need;
+        }
+    }
+
+    void build_binary_frame(size_t f) {
         std::vector<Item> &items = frames_[f];
         // a frame's own depth, the exit marker and the deepest frame below it share the ORDERED_MAX_STACK stack entries
         uint32_t below = 0;

@@ -41,8 +41,10 @@ def test_oracle_is_thread_count_independent(rt, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("name", list(GOLD))
-def test_gpu_matches_golden(rt, gpu, name):
+def test_gpu_matches_golden(rt, gpu, name, wide):
+    """(wide: the library's own trees with two or with four children per record, rt_scene_options.wide)"""
     hs = scene_cases.build(rt, name)
-    out = rt.DeviceScene(hs).render(rt.render_params(seed=GOLD[name]["seed"]))
+    out = rt.DeviceScene(hs, wide=wide).render(rt.render_params(seed=GOLD[name]["seed"]))
     check(rt, hs, out, GOLD[name])

@@ -20,12 +20,12 @@ def check(rt, oracle, scene, what):
     params = rt.render_params(seed=3)
     want = oracle.render(scene, params)
     for ordered in (2, 0):  # 2: own trees wherever the scene allows it; 0: reference order
-        for leaf in ((1, 2, 4, 8) if ordered else (0,)):
-            ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[ordered]), leaf_max=leaf)
+        for leaf, wide in (((1, 0), (2, 0), (4, 0), (8, 0), (1, 1), (3, 1), (8, 1)) if ordered else ((0, 0),)):  # (wide: four children per record)
+            ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[ordered]), leaf_max=leaf, wide=wide)
             assert ds.stats()["ordered"] == (1 if ordered else 0)
             got = ds.render(params)
             bad = np.flatnonzero(bits(got) != bits(want))
-            assert bad.size == 0, f"{what}: ordered={ordered} leaf={leaf}: {bad.size} of {want.size} values differ, first at {bad[:4]}"
+            assert bad.size == 0, f"{what}: ordered={ordered} leaf={leaf} wide={wide}: {bad.size} of {want.size} values differ, first at {bad[:4]}"
 
 
 @pytest.mark.parametrize("order", [0, 1, 2])
@@ -121,9 +121,9 @@ def test_random_object_graphs(rt, oracle, gpu):
     for seed in range(40):
         scene = custom_scenes.random_scene(cam, seed)
         want = oracle.render(scene, params)
-        for ordered in (2, 0):
-            ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[ordered]))
-            ordered_seen += ds.stats()["ordered"]
+        for ordered in (2, 3, 0):  # (3: own trees with four children per record)
+            ds = rt.DeviceScene(scene, walk=getattr(rt, WALKS[min(ordered, 2)]), wide=1 if ordered == 3 else 0)
+            ordered_seen += ds.stats()["ordered"] if ordered != 3 else 0
             got = ds.render(params)
             bad = np.flatnonzero(bits(got) != bits(want))
             assert bad.size == 0, f"random scene {seed}, ordered={ds.stats()['ordered']}: {bad.size} of {want.size} values differ"

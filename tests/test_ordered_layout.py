@@ -204,3 +204,16 @@ def test_small_frames_keep_their_primitives_in_one_leaf(rt):
     # random-spheres (485 spheres) is a tree as before: only frames of <= 8 primitives go flat
     assert len(rt.debug_ordered_layout(scene_cases.build(rt, "c1_random_balls_400x225_10spp_d10"))["nodes"]) == 484
     assert len(rt.debug_ordered_layout(hs, flat_max=0)["nodes"]) == 17
+
+
+def test_four_child_records_hold_every_primitive_once(rt):
+    """rt_scene_options.wide: the binary trees collapsed to records of four children (rt_ordered.hpp widen) — every primitive in exactly
+    one leaf, every child record's boxes inside its slot's box, empty slots closed to every ray; half the records, half the stack."""
+    for name in scene_cases.CASES:
+        hs = scene_cases.build(rt, name)
+        for opts in ({}, {"flat_max": 0}, {"leaf_max": 4}):
+            st = rt.debug_wide_layout(hs, **opts)
+            media_boundaries = 2 if "final_scene" in name else 0  # (solved in place: in no leaf)
+            assert st["violations"] == 0 and st["found"] == st["primitives"] - media_boundaries, (name, opts, st)
+    st = rt.debug_wide_layout(scene_cases.build(rt, "c1_random_balls_400x225_10spp_d10"))
+    assert st["records"] <= 0.5 * 484 and st["stack_entries"] <= 7 and st["deepest"] <= 7, st
