@@ -408,7 +408,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // ---- one WIDE record (rt_layout.h ONode4): four boxes at once, on with the nearest child that is hit; if others are hit too the
     // record itself is set aside with the mask of those — they are looked at again when its turn comes, against the interval as it has
     // shrunk by then (a child missed now is missed then: it leaves the mask for good)
-    auto visit_wide = [&]() {
+    auto visit_wide = [&](bool any_degenerate) { // (any_degenerate: wave-uniform, some lane's ray is — rays do not change inside the box loop)
         if constexpr (ORDERED && WIDE) {
             const uint32_t nid = node & W_INDEX;
             const uint32_t todo = (node >> W_SHIFT) & 0xfu;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 key[k] = __float_as_uint(en[k]) | missed[k] | (uint32_t)((int32_t)(~todo << (31u - k)) >> 31);
             }
             uint32_t hit = ~miss_bits & todo;
-            if (__ballot(r32.degenerate) != 0ull) { // a ray with a zero or infinite direction component: every box that exists is entered
+            if (any_degenerate) { // a ray with a zero or infinite direction component: every box that exists is entered
                 if (r32.degenerate) {
                     hit = 0;
         #pragma unroll
@@ -548,9 +548,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             // ---------------- box test + dispatch on the record kind ----------------
             // stays in this loop (one ballot per round) while enough of the wave's live lanes are walking boxes
             uint32_t in_box;
+            const bool any_degenerate = ORDERED && WIDE && __ballot(r32.degenerate) != 0ull;
             do {
                 if constexpr (ORDERED) {
-                    if (stage == ST_BOX) { if constexpr (WIDE) visit_wide(); else visit_record(); }
+                    if (stage == ST_BOX) { if constexpr (WIDE) visit_wide(any_degenerate); else visit_record(); }
                 } else {
                     if (stage == ST_BOX) {
                         const NodeData nd = load_node<LDS>(P, lds_raw, node);
