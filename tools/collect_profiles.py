@@ -42,7 +42,21 @@ def counters(run):
 
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
 hbm = {}
-for w in ("c1", "c2", "c3", "c4"):
+for w in ("c1", "c2", "c3", "c4", "c5"):
+    if w == "c5":  # one GPU's frame of the 8-GPU configuration: bench line and HBM traffic only
+        if not (SRC / "bench_c5.json").exists():
+            continue
+        shutil.copy(SRC / "bench_c5.json", DST / f"{tag}_bench_c5_1gpu.json")
+        fetch, write = counters("fetch_c5"), counters("write_c5")
+        traffic = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+        bench = json.load(open(SRC / "bench_c5.json"))
+        hbm[w] = {"bytes_per_launch": traffic, "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
+                  "dispatches_per_frame": fetch["_dispatches_per_frame"],
+                  "achieved_GBps": round(traffic / (bench["roofline"]["kernel_ms"] * 1e-3) / 1e9, 1),
+                  "formula": "as c1..c4", "kernel": fetch["_kernel"], "tag": f"{tag} ({commit})",
+                  "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline"}
+        print("c5", bench["value"], "Msamples/s; HBM", round(traffic / 1e9, 2), "GB/frame")
+        continue
     shutil.copy(SRC / f"bench_{w}.json", DST / f"{tag}_bench_{w}.json")
     if (SRC / f"stage_{w}.txt").exists():
         text = "\n".join(l for l in (SRC / f"stage_{w}.txt").read_text().splitlines() if "amdgpu.ids" not in l)
@@ -77,5 +91,7 @@ for w in ("c1", "c2", "c3", "c4"):
     print(w, bench["value"], "Msamples/s; HBM", round(traffic / 1e9, 2), "GB/frame =", hbm[w]["achieved_GBps"], "GB/s; VALU lane utilisation",
           round(sq["valu_lane_utilisation"], 3), "WAIT_INST_ANY share", round(sq["wait_inst_any_share_of_wave_cycles"], 3))
 (DST / "hbm_traffic.json").write_text(json.dumps(hbm, indent=1) + "\n")
+if (SRC / "timeline_c4.txt").exists():
+    shutil.copy(SRC / "timeline_c4.txt", DST / f"{tag}_c4_timeline.txt")
 if (SRC / "kernel_usage.txt").exists():
     shutil.copy(SRC / "kernel_usage.txt", DST / f"{tag}_kernel_usage.txt")

@@ -28,6 +28,13 @@ for w in c2 c3 c4 c1; do
   fi
   echo "profiles $w done"
 done
+# C4's dispatch timeline (the last frame of the kernel trace above): render kernels back to back, sum_samples hidden
+python3 tools/kernel_gaps.py "$OUT/kt_c4" > "$OUT/timeline_c4.txt" 2>&1 || true
+# C5 (final_scene 1600x1600, 10000 spp, depth 50) on this one GPU: the bench line and the HBM traffic of one frame (26 s each)
+timeout -k 10 400 python3 bench.py --workload c5 --steps 1 --warmup 0 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || exit 1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c5" -- python3 bench.py --workload c5 --no-cpu-baseline --steps 1 --warmup 0 > "$OUT/fetch_c5.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c5" -- python3 bench.py --workload c5 --no-cpu-baseline --steps 1 --warmup 0 > "$OUT/write_c5.log" 2>&1 || exit 1
+echo "c5 done"
 python3 tools/kernel_usage.py "path_kernel<false" > "$OUT/kernel_usage.txt" 2>&1 || true
 # keep the merged-back payload small: only the csv summaries
 find "$OUT" -name "*.db" -delete 2>/dev/null
