@@ -517,6 +517,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         if (stage == ST_SHADE && best_prim == PRIM_NONE) stage = ST_NEWJOB + TERM_BACKGROUND;
         // th_new == 0: no separate path-end rounds — every shade round ends with the path-end block (for its own lanes that
         // just finished and any that were waiting), and the two queues count as one (measured better on final_scene)
+        // (the five thresholds travel in ONE scalar register — th_pack: prim | other << 8 | shade << 16 | box << 24, th_new apart: as five
+        // kernel arguments one of them was re-read from the argument segment, with a wait, in every pass through here)
+        const uint32_t th_pack = P.th_pack;
+        const uint32_t th_prim = th_pack & 0xffu, th_other = (th_pack >> 8) & 0xffu, th_shade = (th_pack >> 16) & 0xffu, th_box = th_pack >> 24;
         const bool merged = P.th_new == 0; // (the every-feature presets keep it merged: measured best on final_scene, tools/tune.py)
         const uint32_t n_shade = (uint32_t)__popcll(__ballot(stage == ST_SHADE));
         const uint32_t n_new = (uint32_t)__popcll(__ballot(stage - ST_NEWJOB < 4u));
@@ -526,10 +530,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         if (live == 0) break;
         uint32_t run = ST_BOX, best_c = 0;
         // a deferred stage becomes runnable once its queue holds th/64 of the live lanes ...
-        if (c_sph * 64u >= P.th_prim * live && c_sph > best_c) { run = ST_SPHERE; best_c = c_sph; }
-        if (c_quad * 64u >= P.th_prim * live && c_quad > best_c) { run = ST_QUAD; best_c = c_quad; }
-        if (c_oth * 64u >= P.th_other * live && c_oth > best_c) { run = ST_OTHER; best_c = c_oth; }
-        if (c_shade * 64u >= P.th_shade * live && c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
+        if (c_sph * 64u >= th_prim * live && c_sph > best_c) { run = ST_SPHERE; best_c = c_sph; }
+        if (c_quad * 64u >= th_prim * live && c_quad > best_c) { run = ST_QUAD; best_c = c_quad; }
+        if (c_oth * 64u >= th_other * live && c_oth > best_c) { run = ST_OTHER; best_c = c_oth; }
+        if (c_shade * 64u >= th_shade * live && c_shade > best_c) { run = ST_SHADE; best_c = c_shade; }
         if (c_new * 64u >= P.th_new * live && c_new > best_c) { run = ST_NEWJOB; best_c = c_new; }
         if (best_c == 0 && c_box == 0) { // ... or when nothing else can run
             run = ST_SPHERE; best_c = c_sph;
@@ -575,8 +579,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                 }
                 in_box = (uint32_t)__popcll(__ballot(stage == ST_BOX));
-                if (COUNT && in_box * 64u >= P.th_box * live && in_box > 0) { prof_add(ST_BOX, 0u, 1); prof_add(ST_BOX, 1u, in_box); }
-            } while (in_box * 64u >= P.th_box * live && in_box > 0);
+                if (COUNT && in_box * 64u >= th_box * live && in_box > 0) { prof_add(ST_BOX, 0u, 1); prof_add(ST_BOX, 1u, in_box); }
+            } while (in_box * 64u >= th_box * live && in_box > 0);
         } else if (HAS_SPHERES && run == ST_SPHERE) {
             // ---------------- Sphere::hit (src/sphere.rs:58-83), one sphere per round ----------------
             if (stage == ST_SPHERE) {

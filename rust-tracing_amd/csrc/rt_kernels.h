@@ -61,6 +61,7 @@ struct KParams {
     uint32_t n_local_tiles;
     uint32_t th_prim, th_other, th_shade, th_new; // scheduler thresholds, in 64ths of the live lanes
     uint32_t th_box;                // the box loop keeps running while this many 64ths of the live lanes are in it
+    uint32_t th_pack;               // path_kernel reads the four above from here: prim | other << 8 | shade << 16 | box << 24 (each <= 255)
     uint32_t defer_instances;       // ordered walk: 1 = the world frame's Translate/RotateY subtrees are walked after the world's own tree (path_kernel)
     // LDS-resident scene (SCENE_IN_LDS kernels): image to copy in, and where its parts start (bytes)
     const uint4 *lds_image;
