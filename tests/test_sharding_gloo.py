@@ -65,3 +65,17 @@ def test_tile_shards_gather_into_the_single_process_frame(rt, oracle, tmp_path, 
     # every tile went to exactly one shard: shard sizes add up to the tile count
     tiles = ((w + 7) // 8) * ((h + 7) // 8)
     assert sum(rt.out_size(w, h, rt.RT_OUT_TILES, r, world) for r in range(world)) == tiles * 64 * 3
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu(rt):
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): the script decides from its arguments alone, before touching
+    any GPU, to run torch.distributed.run with two ranks of itself as a child.  Without a GPU every rank then stops at the renderer's
+    'no HIP device' error — which is what this CPU test can see of it (the GPU suite runs the same command to the end)."""
+    if rt.amd_lib().rt_device_count() > 0:
+        pytest.skip("covered by tests/test_gpu_cli.py on a GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "c1", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode != 0
+    assert r.stderr.count("no HIP device for this rank") >= 2, r.stderr[-1500:]  # both ranks were started and got that far
+    assert "must be launched with" not in r.stderr
