@@ -180,3 +180,21 @@ def test_more_materials_than_a_parked_index_can_name(rt, oracle, gpu):
     for opts in (dict(walk=rt.RT_WALK_REFERENCE_ORDER), dict(walk=rt.RT_WALK_OWN_TREES, wide=0), dict(walk=rt.RT_WALK_OWN_TREES, wide=1)):
         got = rt.DeviceScene(scene, **opts).render(params)
         assert (bits(got) == bits(want)).all(), opts
+
+
+@pytest.mark.parametrize("n,level", [(300, 3), (1200, 1), (6000, 0)])
+def test_scenes_at_every_lds_level_in_both_record_forms(rt, oracle, gpu, n, level):
+    """n spheres as one flat list: everything in the LDS (300), only the records (1200), nothing (6000) — each walked through records of
+    two and of four children, and in the reference's order."""
+    cam = scene_cases.build(rt, "quads_64x64_8spp")
+    scene = custom_scenes.many_spheres_scene(cam, n)
+    params = rt.render_params(seed=3)
+    want = oracle.render(scene, params)
+    for opts in (dict(walk=rt.RT_WALK_OWN_TREES, wide=0), dict(walk=rt.RT_WALK_OWN_TREES, wide=1), dict(walk=rt.RT_WALK_REFERENCE_ORDER)):
+        ds = rt.DeviceScene(scene, **opts)
+        if opts.get("wide") == 1:
+            assert rt.debug_last_launch is not None and (ds.stats()["lds_nodes"] > 0) == (level > 0), ds.stats()
+        got = ds.render(params)
+        assert (bits(got) == bits(want)).all(), (n, opts)
+        if opts.get("wide") == 1:
+            assert rt.debug_last_launch()["lds_level"] == level, rt.debug_last_launch()
