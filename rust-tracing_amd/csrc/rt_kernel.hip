@@ -91,11 +91,33 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // the world-frame ray of a lane while it walks inside an instance (Translate / RotateY subtree) is parked in the LDS where
     // the scene leaves room (Cornell: a frame exit waited for six loads from memory, a fifth of the frame's cycles went there),
     // else in global memory (touched 0.3-2.6 times per sample)
+    // (in the kernels that are short of registers the slot addresses are formed where they are used, from a lane index the optimiser
+    // cannot look behind: hoisted out of the main loop the twelve of them — six per memory — sat in 24 registers from the kernel's first
+    // instruction to its last, or in scratch: every-feature kernel 168 registers + 20-42 spilled -> 167-168 + 0-2)
+    constexpr bool SLOTS_AT_USE = HAS_TEXTURES || HAS_MEDIA; // (the other kernels have the registers and change frames often: Cornell
+    // 2448 Msamples/s with the addresses kept, 2401-2425 with them formed at use; final_scene, 0.3 frame changes per sample: 1090 / 1117)
     const bool world_in_lds = P.lds_world_off != 0xffffffffu;
     double *const world_lds = reinterpret_cast<double *>(lds_raw + (world_in_lds ? P.lds_world_off : 0u)) + threadIdx.x;
     double *const world_glb = P.world_slots + gtid;
+    auto slot_lane = [&]() -> uint32_t {
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
     auto park_world_ray = [&](V3 po, V3 pd) {
-        if (world_in_lds) {
+        if constexpr (SLOTS_AT_USE) {
+            const uint32_t t = slot_lane();
+            if (P.lds_world_off != 0xffffffffu) { // (two branches, not one selected pointer: each keeps its address space)
+                double *const w = reinterpret_cast<double *>(lds_raw + P.lds_world_off) + t;
+                w[0] = po.x; w[THREADS] = po.y; w[2 * THREADS] = po.z;
+                w[3 * THREADS] = pd.x; w[4 * THREADS] = pd.y; w[5 * THREADS] = pd.z;
+            } else {
+                double *const w = P.world_slots + (blockIdx.x * blockDim.x + t);
+                const size_t ws = P.n_threads;
+                w[0] = po.x; w[ws] = po.y; w[2 * ws] = po.z;
+                w[3 * ws] = pd.x; w[4 * ws] = pd.y; w[5 * ws] = pd.z;
+            }
+        } else if (world_in_lds) {
             world_lds[0] = po.x; world_lds[THREADS] = po.y; world_lds[2 * THREADS] = po.z;
             world_lds[3 * THREADS] = pd.x; world_lds[4 * THREADS] = pd.y; world_lds[5 * THREADS] = pd.z;
         } else {
@@ -105,7 +127,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         }
     };
     auto restore_world_ray = [&](V3 &ro, V3 &rd) {
-        if (world_in_lds) {
+        if constexpr (SLOTS_AT_USE) {
+            const uint32_t t = slot_lane();
+            if (P.lds_world_off != 0xffffffffu) {
+                const double *const w = reinterpret_cast<const double *>(lds_raw + P.lds_world_off) + t;
+                ro = v3(w[0], w[THREADS], w[2 * THREADS]);
+                rd = v3(w[3 * THREADS], w[4 * THREADS], w[5 * THREADS]);
+            } else {
+                const double *const w = P.world_slots + (blockIdx.x * blockDim.x + t);
+                const size_t ws = P.n_threads;
+                ro = v3(w[0], w[ws], w[2 * ws]);
+                rd = v3(w[3 * ws], w[4 * ws], w[5 * ws]);
+            }
+        } else if (world_in_lds) {
             ro = v3(world_lds[0], world_lds[THREADS], world_lds[2 * THREADS]);
             rd = v3(world_lds[3 * THREADS], world_lds[4 * THREADS], world_lds[5 * THREADS]);
         } else {
