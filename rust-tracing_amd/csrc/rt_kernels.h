@@ -117,7 +117,9 @@ constexpr int GLOBAL_THREADS = 256;             // scene gathered from global me
 #endif
 constexpr int LDS_THREADS = RT_LDS_THREADS;     // scene in LDS: one 16-wave workgroup per CU shares the copy
 #ifndef RT_LDS_THREADS_GENERAL
-#define RT_LDS_THREADS_GENERAL 768 // the every-feature kernels: 12 waves = 3 per SIMD, 170 registers each (at 128 they spill 80-140 of them)
+#define RT_LDS_THREADS_GENERAL 1024 // the every-feature kernels: 16 waves = 4 per SIMD at 128 registers.  (Rounds 1-2: 768 threads, 3 per SIMD at 168 registers —
+// at 128 they spilled 80-141 of them; with the parked indices, the parameters and the slot addresses read at use they spill 0-75, nearly all of it in cold
+// code, and the fourth wave pays: cornell_smoke 1296 -> 1465 Msamples/s, two_perlin_spheres 4663 -> 5082, simple_light 5684 -> 5871, earth 21733 -> 20800)
 #endif
 constexpr int LDS_THREADS_GENERAL = RT_LDS_THREADS_GENERAL;
 #ifndef RT_QUADS_FRAMES_THREADS
