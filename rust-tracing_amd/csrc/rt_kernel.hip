@@ -42,8 +42,10 @@ enum Stage : uint32_t { ST_BOX = 0, ST_SPHERE = 1, ST_QUAD = 2, ST_OTHER = 3, ST
 enum Terminal : uint32_t { TERM_BACKGROUND = 0, TERM_ONE = 1, TERM_ZERO = 2, TERM_STORED = 3 };
 
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4 // waves per SIMD the register allocator must leave room for in the kernels that gather the scene from global memory
-// (rounds 1-2: 3 — at 128 registers the every-feature kernel spilled 80-141; now 63-75, none of it in the box loop: final_scene 1114 -> 1136 Msamples/s)
+#define RT_MIN_WAVES 3 // waves per SIMD the register allocator must leave room for in the kernels that gather the scene from global memory.
+// (Measured again in round 3 with 4: the every-feature kernel then spills 63-75 registers instead of 0-2 — none in the box loop — and
+// final_scene runs 2 % faster, 1114 -> 1136 Msamples/s, but the spills' scratch traffic takes its HBM bytes from 476 GB to 2.4 TB per
+// frame: not worth it.  The LDS-resident every-feature kernels, whose scenes are small, do run four waves: rt_kernels.h.)
 #endif
 
 // LDS: 0 = scene gathered from global memory; 1 = node table in LDS; 2 = + sphere table; 3 = + quad table
