@@ -741,11 +741,15 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
             for (int l = s->lds_level + 1; l < 4; ++l) s->lds_prefix_bytes[l] = 0;
         }
     }
-    // (one entry more than the scene has materials: Color::ONE, what the path end multiplies by for a level a path does not have)
-    std::vector<DMaterial> mats(cs.materials.size() + 1u);
-    mats.back().albedo[0] = mats.back().albedo[1] = mats.back().albedo[2] = 1.0;
-    mats.back().solid = 1u;
-    for (size_t i = 0; i + 1u < mats.size(); ++i) {
+    // (one entry more than the scene has materials: Color::ONE, what the path end multiplies by for a level a path does not have;
+    // two more where the one's index would be 0xffff, the mark of a parked colour)
+    const size_t n_mats = cs.materials.size();
+    std::vector<DMaterial> mats(n_mats + (n_mats == 0xffffu ? 2u : 1u));
+    for (size_t i = n_mats; i < mats.size(); ++i) {
+        mats[i].albedo[0] = mats[i].albedo[1] = mats[i].albedo[2] = 1.0;
+        mats[i].solid = 1u;
+    }
+    for (size_t i = 0; i < n_mats; ++i) {
         const rt_material &m = cs.materials[i];
         DMaterial d{};
         d.kind = (uint32_t)m.kind;

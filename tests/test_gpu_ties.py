@@ -160,20 +160,23 @@ def test_walk_shortcuts_never_change_the_image(rt, oracle, gpu, shortcuts):
         assert bad.size == 0, f"{name}, shortcuts {shortcuts}: {bad.size} of {want.size} values differ"
 
 
-def test_more_materials_than_a_parked_index_can_name(rt, oracle, gpu):
-    """Parked attenuations are 16-bit material indices; a scene with 66 000 materials (most of them unused, the used ones spread over
-    the whole range) is rendered by the kernels that park colours instead — same image as the oracle's, in every walk."""
+@pytest.mark.parametrize("n_lambertian", [65532, 65533, 66000])
+def test_more_materials_than_a_parked_index_can_name(rt, oracle, gpu, n_lambertian):
+    """Parked attenuations are 16-bit material indices; a scene with 65 534 materials still parks indices, one with 65 535 (the table's
+    Color::ONE entry would get the index that marks a parked colour) or 66 002 (most of them unused, the used ones spread over the whole
+    range) is rendered by the kernels that park colours instead — same image as the oracle's, in every walk."""
     import random
     cam = scene_cases.build(rt, "quads_64x64_8spp")
     rnd = random.Random(3)
     s = custom_scenes.CustomScene(cam, spp=4, depth=12, background=(0.7, 0.8, 1.0))
-    mats = [s.lambertian(rnd.random(), rnd.random(), rnd.random()) for _ in range(66000)]
+    mats = [s.lambertian(rnd.random(), rnd.random(), rnd.random()) for _ in range(n_lambertian)]
     mats += [s.metal(0.9, 0.8, 0.7, 0.1), s.dielectric(1.5)]
-    pick = [mats[0], mats[1], mats[65533], mats[65534], mats[65535], mats[65536], mats[65999], mats[66000], mats[66001]]
+    n = len(mats)
+    pick = [mats[0], mats[1], mats[65530], mats[65531], mats[n // 2], mats[n - 4], mats[n - 3], mats[n - 2], mats[n - 1]]
     items = [s.sphere((0.0, -1003.0, 0.0), 1000.0, mats[40000])]
     for k in range(40):
         items.append(s.sphere((rnd.uniform(-4, 4), rnd.uniform(-2.5, 1.5), rnd.uniform(-4, 2)), rnd.uniform(0.3, 0.8), pick[k % len(pick)]))
-    items.append(s.quad((-5.0, -3.0, -5.0), (10.0, 0.0, 0.0), (0.0, 6.0, 0.0), mats[65535]))
+    items.append(s.quad((-5.0, -3.0, -5.0), (10.0, 0.0, 0.0), (0.0, 6.0, 0.0), mats[n - 5]))
     scene = s.finish(s.list(items))
     params = rt.render_params(seed=3)
     want = oracle.render(scene, params)
