@@ -61,7 +61,7 @@ uint64_t host_mix64(uint64_t z) {
 
 uint32_t lds_image_bytes_for(const rt_scene *s, int lds) { return s->lds_prefix_bytes[lds]; }
 // the LDS image, then (ordered walk) the per-lane stacks: 2-byte entries beside an LDS-resident scene, else 4-byte
-int block_threads(const rt_scene *s, int lds) { return kernel_threads_for(kernel_features_for(s->features, lds, s->ordered), lds); }
+int block_threads(const rt_scene *s, int lds) { return kernel_threads_for(kernel_features_for(s->features, lds, s->ordered), lds, s->ordered); }
 size_t stack_bytes(const rt_scene *s, int lds) {
     if (!s->ordered) return 0;
     return (size_t)s->o_stack * (size_t)block_threads(s, lds) * (lds ? 2u : 4u);

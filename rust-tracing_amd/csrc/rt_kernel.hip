@@ -1231,9 +1231,10 @@ uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered) {
     }
     return F_ALL;
 }
-int kernel_threads_for(uint32_t kernel_features, int lds) {
+int kernel_threads_for(uint32_t kernel_features, int lds, bool ordered) {
     if (lds == 0) return GLOBAL_THREADS;
     if (kernel_features == FEAT_QUADS_FRAMES) return QUADS_FRAMES_THREADS;
+    if (kernel_features == FEAT_SPHERES_QUADS_TEXTURES && !ordered) return REFERENCE_TEXTURES_THREADS;
     return kernel_features == FEAT_SPHERES_SOLID ? LDS_THREADS : LDS_THREADS_GENERAL;
 }
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux, bool wide) {
@@ -1255,7 +1256,7 @@ const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, 
         if (feat == FEAT_SPHERES_SOLID) return RT_PICK(3, LDS_THREADS, FEAT_SPHERES_SOLID, false, false);
         if (feat == FEAT_QUADS_FRAMES) return RT_PICK(3, QUADS_FRAMES_THREADS, FEAT_QUADS_FRAMES, false, false);
         if (feat == FEAT_QUADS_FRAMES_MEDIA) return RT_PICK(3, LDS_THREADS_GENERAL, FEAT_QUADS_FRAMES_MEDIA, false, false);
-        if (feat == FEAT_SPHERES_QUADS_TEXTURES) return RT_PICK(3, LDS_THREADS_GENERAL, FEAT_SPHERES_QUADS_TEXTURES, false, false);
+        if (feat == FEAT_SPHERES_QUADS_TEXTURES) return RT_PICK(3, REFERENCE_TEXTURES_THREADS, FEAT_SPHERES_QUADS_TEXTURES, false, false);
         return RT_PICK(3, LDS_THREADS_GENERAL, F_ALL, false, false);
     }
     if (lds == 2) return RT_PICK(2, LDS_THREADS_GENERAL, F_ALL, false, false);

@@ -119,13 +119,19 @@ constexpr int LDS_THREADS = RT_LDS_THREADS;     // scene in LDS: one 16-wave wor
 #ifndef RT_LDS_THREADS_GENERAL
 #define RT_LDS_THREADS_GENERAL 1024 // the every-feature kernels: 16 waves = 4 per SIMD at 128 registers.  (Rounds 1-2: 768 threads, 3 per SIMD at 168 registers —
 // at 128 they spilled 80-141 of them; with the parked indices, the parameters and the slot addresses read at use they spill 0-75, nearly all of it in cold
-// code, and the fourth wave pays: cornell_smoke 1296 -> 1465 Msamples/s, two_perlin_spheres 4663 -> 5082, simple_light 5684 -> 5871, earth 21733 -> 20800)
+// code, and the fourth wave pays: cornell_smoke 1296 -> 1465 Msamples/s, two_perlin_spheres 4663 -> 5082, simple_light 5684 -> 5871; the reference-order texture kernel is the exception, below)
 #endif
 constexpr int LDS_THREADS_GENERAL = RT_LDS_THREADS_GENERAL;
 #ifndef RT_QUADS_FRAMES_THREADS
 #define RT_QUADS_FRAMES_THREADS RT_LDS_THREADS // the quads + frames kernel (Cornell): 128 registers with 6-10 spilled at 1024 threads; tools A/B: 768
 #endif
 constexpr int QUADS_FRAMES_THREADS = RT_QUADS_FRAMES_THREADS;
+// spheres + quads + textures in the REFERENCE's order (earth, a one-sphere scene, renders that way by default; the fallback of two_spheres,
+// two_perlin_spheres, simple_light): 12 waves = 3 per SIMD at 168 registers.  At 1024 threads that kernel spills 48 registers in its
+// texture code, which a one-primitive scene runs all the time: earth 17.6 Gsamples/s at 1024 threads, 22.1 at 768 (256 spp; the other
+// three in reference order 5.6 / 2.9 / 5.6 -> 6.7 / 3.2 / 6.0).  The same features on the library's own trees keep 1024 (8.3 / 5.1 / 7.7
+// against 8.1 / 4.8 / 7.3 at 768), and so does every kernel with media (cornell_smoke 1.50 against 1.32; reference order 1.17 / 1.03).
+constexpr int REFERENCE_TEXTURES_THREADS = 768;
 constexpr size_t LDS_BUDGET_BYTES = 160 * 1024; // LDS per CU on MI355X
 
 // The kernel instantiations that exist: the general one (every feature) at each LDS level, plus specialised
@@ -136,7 +142,7 @@ constexpr uint32_t FEAT_QUADS_FRAMES = F_QUADS | F_FRAMES;  // Cornell box: quad
 constexpr uint32_t FEAT_QUADS_FRAMES_MEDIA = F_QUADS | F_FRAMES | F_MEDIA;              // cornell_smoke
 constexpr uint32_t FEAT_SPHERES_QUADS_TEXTURES = F_SPHERES | F_QUADS | F_TEXTURES;    // two_spheres, earth, two_perlin_spheres, simple_light
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
-int kernel_threads_for(uint32_t kernel_features, int lds); // workgroup size of that instantiation
+int kernel_threads_for(uint32_t kernel_features, int lds, bool ordered); // workgroup size of that instantiation
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux, bool wide);
 const void *pool_kernel_for(uint32_t feat, bool aux, bool prof); // ordered, LDS-resident scenes (lds level 3)
 size_t pool_ctl_bytes();
