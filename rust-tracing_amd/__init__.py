@@ -247,7 +247,7 @@ RT_AMD_DEBUG_SYMBOLS = {
 }
 
 RT_DEBUG_LOG, RT_DEBUG_SIN, RT_DEBUG_ACOS, RT_DEBUG_ATAN2, RT_DEBUG_POW5, RT_DEBUG_SQRT, RT_DEBUG_DIV, \
-    RT_DEBUG_MUL_ADD, RT_DEBUG_RNG_RANDOM, RT_DEBUG_RNG_RANGE = range(1, 11)
+    RT_DEBUG_MUL_ADD, RT_DEBUG_RNG_RANDOM, RT_DEBUG_RNG_RANGE, RT_DEBUG_F32_ABOVE, RT_DEBUG_F32_BELOW = range(1, 13)
 
 
 def debug_box_tests(rays, boxes, tmin, tmax, device=0):

@@ -40,6 +40,21 @@ RT_DEV V3 refract(V3 v, V3 n, double etai_over_etat) {                          
     return r_out_perp + r_out_parallel;
 }
 
+// A float not below (f32_above) / not above (f32_below) the double x, at most 1.5 ulps away: x rounded to nearest, then moved by more
+// than half an ulp and at most one — 2^-24 (1 + 2^-23) |f|; exactly half would be lost to the tie at a power of two — and by the
+// smallest normal float on top (which only shows below 2^-102: an x that rounds to zero).  The rounded value is first clamped to
+// +-FLT_MAX, so that an x beyond the float range, infinite or not, ends at the right infinity on its outer side and at a finite float
+// on its inner side (inf x 2^-24 - inf would be a NaN; -inf is not above -1e300).  Four instructions where the exact directed rounding
+// (__double2float_ru / _rd: a conversion and an integer next-after with its special cases) takes sixteen; the ordered walk's box test
+// only needs an interval that CONTAINS (cur_tmin, cur_tmax), not the tightest one (tests/test_gpu_parity.py checks both properties).
+RT_DEV float f32_above(double x) {
+    const float f = __builtin_amdgcn_fmed3f((float)x, -0x1.fffffep+127f, 0x1.fffffep+127f);
+    return __builtin_fmaf(__builtin_fabsf(f), 0x1.000002p-24f, f) + 0x1p-126f;
+}
+RT_DEV float f32_below(double x) {
+    const float f = __builtin_amdgcn_fmed3f((float)x, -0x1.fffffep+127f, 0x1.fffffep+127f);
+    return __builtin_fmaf(__builtin_fabsf(f), -0x1.000002p-24f, f) - 0x1p-126f;
+}
 RT_DEV uint64_t f2u(double x) { return (uint64_t)__double_as_longlong(x); }
 RT_DEV double u2f(uint64_t u) { return __longlong_as_double((long long)u); }
 

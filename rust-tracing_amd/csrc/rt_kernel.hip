@@ -300,8 +300,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     };
     // (the ordered walk's test takes the interval rounded outward; the threaded one has the slack for either rounding)
     auto refresh_interval32 = [&]() {
-        tmin32 = ORDERED ? __double2float_rd(cur_tmin) : (float)cur_tmin;
-        tmax32 = ORDERED ? __double2float_ru(cur_tmax) : (float)cur_tmax;
+        tmin32 = ORDERED ? f32_below(cur_tmin) : (float)cur_tmin;
+        tmax32 = ORDERED ? f32_above(cur_tmax) : (float)cur_tmax;
     };
 
     // ---- ConstantMedium::hit (src/constant_medium.rs:33-71), shared by both walks ----
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 seq_pc++;
                 float enter;
                 bool miss0, miss1;
-                box_pair_f32(opair_of_box(rec->box, r32), r32, __double2float_rd(cur_tmin), __double2float_ru(cur_tmax), miss0, miss1, enter, enter);
+                box_pair_f32(opair_of_box(rec->box, r32), r32, f32_below(cur_tmin), f32_above(cur_tmax), miss0, miss1, enter, enter);
                 if (miss0) continue;
                 if (rec->kind == OSEQ_TREE) {
                     node = rec->a | W_FULL; sp = 0; stage = ST_BOX;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                     if (ok) {
                         cur_tmax = root;
-                        tmax32 = ORDERED ? __double2float_ru(root) : (float)root;
+                        tmax32 = ORDERED ? f32_above(root) : (float)root;
                         if (!HAS_MEDIA || (mode & 3u) == 0) { if (HAS_MEDIA) best_t = root; best_prim = PRIM_SPHERE | q; best_inst = cur_inst; }
                         else mode |= 0x100u;
                     }
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const double beta = dot(qw, cross(ld3(qd->u), php));
                     if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
                     cur_tmax = t;
-                    tmax32 = ORDERED ? __double2float_ru(t) : (float)t;
+                    tmax32 = ORDERED ? f32_above(t) : (float)t;
                     if (!HAS_MEDIA || (mode & 3u) == 0) { if (HAS_MEDIA) best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
                     else mode |= 0x100u;
                 }
@@ -1211,6 +1211,8 @@ __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restric
     case RT_DEBUG_RNG_RANGE: {
         Rng g; g.start_key(f2u(x)); for (uint64_t i = 0; i < f2u(y); ++i) g.next(); r = g.range(-1.0, 1.0); break;
     }
+    case RT_DEBUG_F32_ABOVE: r = (double)f32_above(x); break;
+    case RT_DEBUG_F32_BELOW: r = (double)f32_below(x); break;
     default: r = 0.0;
     }
     out[idx] = r;

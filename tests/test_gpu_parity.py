@@ -66,6 +66,31 @@ def test_device_arithmetic_matches_oracle(rt, oracle, gpu):
     assert_bit_equal(rt.debug_eval(rt.RT_DEBUG_RNG_RANGE, kf, df), want_g, "gen_range(-1, 1)")
 
 
+def test_outward_f32_conversions_contain_the_double(rt, gpu):
+    """The ordered walk tests boxes against the ray interval converted to f32 OUTWARD (f32_below / f32_above, rt_device_math.h): for every
+    double — huge, tiny, negative, infinite, on and between the floats — the converted end must not lie inside the interval, and must stay
+    within two ulps of it."""
+    rng = np.random.default_rng(7)
+    n = 400_000
+    x = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-50, 45, n)
+    floats = rng.uniform(-1e6, 1e6, 4000).astype(np.float32).astype(np.float64)
+    edge = np.array([0.0, -0.0, 5e-324, -5e-324, 1e-46, -1e-46, 2.0 ** -149, 2.0 ** -126, -(2.0 ** -126), 0.001, 1.0, -1.0, 3.4028234663852886e38,
+                     3.4028235677973366e38, 1e39, -1e39, 1.7976931348623157e308, -1.7976931348623157e308, np.inf, -np.inf])
+    x = np.concatenate([x, floats, np.nextafter(floats, np.inf), np.nextafter(floats, -np.inf), edge])
+    up = rt.debug_eval(rt.RT_DEBUG_F32_ABOVE, x)
+    dn = rt.debug_eval(rt.RT_DEBUG_F32_BELOW, x)
+    assert not np.isnan(up).any() and not np.isnan(dn).any()
+    assert (up >= x).all() and (dn <= x).all()
+    assert (up[np.isposinf(x)] == np.inf).all() and (dn[np.isneginf(x)] == -np.inf).all()
+    assert np.isfinite(up[x < -3.5e38]).all() and np.isfinite(dn[x > 3.5e38]).all()  # (the inner side of a value beyond the float range)
+    # tight: for doubles in the normal float range, no further than two float steps from the double
+    with np.errstate(over="ignore"):
+        f = x.astype(np.float32)
+    ok = np.isfinite(f) & (np.abs(x) > 1e-30) & (np.abs(x) < 1e38)
+    step = np.spacing(np.abs(f[ok])).astype(np.float64)
+    assert ((up[ok] - x[ok]) <= 2.0 * step).all() and ((x[ok] - dn[ok]) <= 2.0 * step).all()
+
+
 def test_f32_box_test_never_misses_what_the_exact_test_enters(rt, gpu):
     """The kernel walks f32 boxes with an error-bounded test; it may enter a box the exact f64 test rejects (a wasted
     visit), never the reverse.  Random and adversarial (grazing, axis-parallel, far-away, tiny-direction) cases."""
