@@ -765,6 +765,14 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         }
         d.fuzz = m.fuzz;
         d.ir = m.ir;
+        if (m.kind == RT_MATERIAL_DIELECTRIC) {
+            // a Dielectric attenuates by Color::ONE and reads no albedo: the three doubles carry what its scatter() divides out on every
+            // hit (src/material.rs:86, :75-77) — the same IEEE operations, done once here: 1 / ir, and Schlick's r0 for either face
+            const double inv_ir = 1.0 / m.ir;
+            double r0_front = (1.0 - inv_ir) / (1.0 + inv_ir), r0_back = (1.0 - m.ir) / (1.0 + m.ir);
+            r0_front = r0_front * r0_front; r0_back = r0_back * r0_back;
+            d.albedo[0] = inv_ir; d.albedo[1] = r0_front; d.albedo[2] = r0_back;
+        }
         mats[i] = d;
     }
 

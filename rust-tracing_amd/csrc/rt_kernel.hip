@@ -856,6 +856,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 const uint32_t park_id = (!HAS_TEXTURES || (P.ids_ok != 0u && (mk == RT_MATERIAL_METAL || m->solid != 0u))) ? mat : ID_COLOUR;
                 bool unit_attenuation = false;
                 V3 new_dir = normal;
+                // Metal and Dielectric both start from the unit direction: one square root and one division for the two branches of a round
+                V3 unit_d = d;
+                if (mk == RT_MATERIAL_METAL || mk == RT_MATERIAL_DIELECTRIC) unit_d = normalize(d);
                 if (mk == RT_MATERIAL_DIFFUSE_LIGHT) { // emitted, no scatter (src/material.rs:114-122)
                     result = tex;
                     path_done = true;
@@ -863,20 +866,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const V3 scatter_direction = normal + normalize(rs);
                     new_dir = near_zero(scatter_direction) ? normal : scatter_direction;
                 } else if (mk == RT_MATERIAL_METAL) { // src/material.rs:53-64
-                    const V3 refl = reflect(normalize(d), normal);
+                    const V3 refl = reflect(unit_d, normal);
                     const V3 reflected = refl + rs * m->fuzz;
                     if (!(dot(reflected, normal) > 0.0)) path_done = true; // absorbed: emission (zero) only
                     new_dir = reflected;
                     attenuation = ld3(m->albedo);
                 } else if (mk == RT_MATERIAL_DIELECTRIC) { // src/material.rs:80-104
-                    const double refraction_ratio = front_face ? 1.0 / m->ir : m->ir;
-                    const V3 unit_direction = normalize(d);
+                    const double refraction_ratio = front_face ? m->albedo[0] : m->ir; // (1.0 / ir and both r0 were divided out when the table was built)
+                    const V3 unit_direction = unit_d;
                     const double cos_theta = __builtin_fmin(dot(-unit_direction, normal), 1.0);
                     const double sin_theta = __builtin_sqrt(1.0 - cos_theta * cos_theta);
                     bool do_reflect = refraction_ratio * sin_theta > 1.0;
                     if (!do_reflect) { // `||` short-circuit: draw only when refraction is possible
-                        double r0 = (1.0 - refraction_ratio) / (1.0 + refraction_ratio);
-                        r0 = r0 * r0;
+                        const double r0 = front_face ? m->albedo[1] : m->albedo[2]; // ((1 - ratio) / (1 + ratio))^2
                         const double reflectance = r0 + (1.0 - r0) * rt_pow5(1.0 - cos_theta);
                         if (COUNT) cn.rng_draws++;
                         do_reflect = reflectance > rng.random();

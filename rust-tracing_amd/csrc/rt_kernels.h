@@ -16,7 +16,7 @@ struct DMaterial { // 64 bytes
     uint32_t texture;
     uint32_t needs_uv; // the texture below reads (u, v): only ImageTexture does (src/texture.rs:83)
     uint32_t solid;    // the texture is a SolidColor: its colour is copied into `albedo` (one dependent load fewer per hit)
-    double albedo[3];  // Metal's albedo, or the SolidColor's colour
+    double albedo[3];  // Metal's albedo, or the SolidColor's colour; a Dielectric's 1 / ir, r0 seen from outside, r0 seen from inside (rt_api.cpp)
     double fuzz;
     double ir;
     uint32_t slow;     // evaluating the texture is dear (Perlin turbulence): see the shade stage
