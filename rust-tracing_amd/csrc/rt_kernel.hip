@@ -205,6 +205,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     constexpr bool DEFER = HAS_FRAMES && ORDERED && !HAS_MEDIA;
     const bool defer = DEFER && P.defer_instances != 0;
     uint32_t deferred = 0;
+    constexpr uint32_t SEQ_JUMP = 0x80000000u; // in seq_pc while a tree is walked: see the look-ahead where a query starts
     auto o_next = [&](bool have, uint32_t ref) {
         uint32_t new_stage, new_node = node, new_cur = prim_cur, new_end = prim_end;
         if (have) {
@@ -227,6 +228,16 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 const bool more = seq_pc < P.n_oseq || (mode & 3u) != 0;
                 new_node = more ? NODE_SEQ_NEXT : node;
                 new_stage = more ? (uint32_t)ST_OTHER : (uint32_t)ST_SHADE;
+                if constexpr (ORDERED) {
+                    // the look-ahead found that the next step this ray can reach is another tree (SEQ_JUMP | its index): on with that
+                    // tree's root at once, not through a round of ST_OTHER that would only have looked the root up
+                    if ((seq_pc & SEQ_JUMP) != 0u) {
+                        const uint32_t k = seq_pc & ~SEQ_JUMP;
+                        new_node = seq_tab[k].a | W_FULL;
+                        new_stage = ST_BOX;
+                        seq_pc = k + 1u;
+                    }
+                }
             }
         }
         stage = new_stage; node = new_node; prim_cur = new_cur; prim_end = new_end;
@@ -1084,15 +1095,19 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 // within the interval it has now (it only shrinks), the sequence ends with the tree that is about to be walked — and
                 // the walk's end goes straight to shading, not through a round of ST_OTHER that finds nothing to do (final_scene: a
                 // quarter of the sequence rounds, 0.86 per sample, did).  Short sequences only: the look-ahead is a loop over the steps.
+                // If the first later step it can reach is a TREE, the walk's end goes on with that tree's root directly (SEQ_JUMP, o_next):
+                // the steps in between stay out of reach — the interval only shrinks — and the tree's own box test is made good by its
+                // root record's (final_scene: the rays that miss the smoke's box but not the second tree's).
                 if (P.seq_lookahead && stage == ST_BOX && mode == 0 && P.n_oseq - seq_pc <= 4u) {
-                    bool reachable = false;
-                    for (uint32_t k = seq_pc; k < P.n_oseq; ++k) {
+                    uint32_t first = P.n_oseq;
+                    for (uint32_t k = P.n_oseq; k-- > seq_pc;) {
                         float enter;
                         bool miss0, miss1;
                         box_pair_f32(opair_of_box(seq_tab[k].box, r32), r32, tmin32, tmax32, miss0, miss1, enter, enter);
-                        reachable = reachable || !miss0;
+                        first = miss0 ? first : k;
                     }
-                    if (!reachable) seq_pc = P.n_oseq;
+                    if (first == P.n_oseq) seq_pc = P.n_oseq;
+                    else if (seq_tab[first].kind == OSEQ_TREE) seq_pc = first | SEQ_JUMP;
                 }
             }
         }
