@@ -970,7 +970,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                 }
                 double *dst = KP->samples + (size_t)job * 3u;
-                dst[0] = result.x; dst[1] = result.y; dst[2] = result.z;
+                __builtin_nontemporal_store(result.x, &dst[0]); __builtin_nontemporal_store(result.y, &dst[1]); __builtin_nontemporal_store(result.z, &dst[2]);
                 stage = ST_NEWJOB + TERM_STORED;
             }
             PROF_MARK(10);
