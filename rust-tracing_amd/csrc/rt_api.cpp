@@ -405,7 +405,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_prof_off = (uint32_t)prof_offset(scene, lds);
     {
         const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? (scene->ordered ? tn.spheres_solid : tn.spheres_threaded) : (kf == FEAT_QUADS_FRAMES ? (scene->insts.bytes ? tn.quads_frames : tn.quads_only) : (scene->ordered ? tn.ordered_general : tn.general)));
+        const Thresholds th = tn.pick(kf == FEAT_SPHERES_SOLID ? (scene->ordered ? tn.spheres_solid : tn.spheres_threaded) : (kf == FEAT_QUADS_FRAMES ? (scene->insts.bytes ? tn.quads_frames : tn.quads_only) : (scene->ordered ? (lds == 0 ? tn.ordered_global : tn.ordered_general) : tn.general)));
         K.th_prim = th.prim; K.th_other = th.other; K.th_shade = th.shade; K.th_box = th.box; K.th_new = th.newjob;
         auto byte = [](uint32_t v) { return v > 255u ? 255u : v; };
         K.th_pack = byte(th.prim) | (byte(th.other) << 8) | (byte(th.shade) << 16) | (byte(th.box) << 24);

@@ -61,6 +61,8 @@ struct Thresholds { uint32_t prim, other, shade, box, newjob; };
 struct Tuning {
     Thresholds general{8, 8, 48, 8, 0};
     Thresholds ordered_general{8, 12, 40, 8, 0}; // every feature, ordered walk (final_scene: 760 vs 745 Msamples/s at 60 spp)
+    Thresholds ordered_global{4, 8, 48, 8, 0};   // ... the same walk with the scene gathered from global memory (final_scene; swept twice on round 3's kernels: +0.4 % over the
+                                                // preset above, which stays for the LDS-resident scenes — cornell_smoke loses 5 % with this one)
     Thresholds spheres_solid{6, 16, 32, 6, 28};  // random-spheres (re-tuned with the start shortcut: 5070 vs 4900 Msamples/s at 50 spp for round 1's 8/16/24/16/32)
     Thresholds quads_frames{24, 16, 48, 2, 0}; // Cornell box (tools/tune.py; with instances walked last and flat leaves the merged path end wins: round 1's 8/16/40/4/8 is 7 % behind)
     Thresholds spheres_threaded{8, 16, 24, 16, 32}; // ... the same kernel walking the reference's order (no shortcut there)
