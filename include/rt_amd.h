@@ -265,7 +265,8 @@ typedef enum rt_walk {
     RT_WALK_OWN_TREES = 2        /* the library's own trees wherever the scene allows it */
 } rt_walk;
 typedef struct rt_scene_options {
-    uint32_t struct_size;        /* sizeof(rt_scene_options): lets the struct grow compatibly */
+    uint32_t struct_size;        /* sizeof(rt_scene_options) as the CALLER was compiled: lets the struct grow compatibly — the library
+                                    reads that many bytes and takes its defaults for every field beyond them */
     int32_t walk;                /* rt_walk */
     int32_t leaf_max;            /* own trees: primitives per leaf at most (<= 0: default) */
     int32_t refit;               /* -1 default (on); 0: keep the reference's boxes; 1: shrink them to the geometry */
@@ -273,9 +274,8 @@ typedef struct rt_scene_options {
     int32_t th_prim, th_other, th_shade, th_box, th_new; /* scheduler thresholds in 64ths of a wave's live lanes; -1: preset */
     int64_t sample_buffer_bytes; /* per-(scene, stream) sample buffer at most; <= 0: default (2 GiB).  A frame that needs
                                     more is rendered in several launches over sample sub-ranges (same result). */
-    int32_t pool;                /* -1 default (off); 1: render with the pool kernel where the scene allows it (LDS-resident, own
-                                    trees): paths move between walking lanes and full-width shading rounds through a slot pool in
-                                    the LDS (DESIGN.md "Ray compaction across stages"); 0: never */
+    int32_t reserved_pool;       /* ignored (rounds 2-3: the opt-in pool kernel, measured at 0.55x and removed — DESIGN_HISTORY.md); keeps
+                                    the offsets of the fields below */
     int32_t flat_max;            /* own trees: a frame of at most this many primitives of one kind keeps them in one leaf under its root
                                     (0: off; -1: default, 8) */
     /* how the walk of the library's own trees starts and ends its queries (each -1: default) */
@@ -287,7 +287,11 @@ typedef struct rt_scene_options {
     int32_t wide;                /* own trees: 1: records of four children, 0: of two; -1: default — four for scenes of 64 primitives or
                                     more (DESIGN.md "Wide records") */
 } rt_scene_options;
+/* Fills the defaults.  rt_scene_options_init writes sizeof(rt_scene_options) of THIS header: caller and library must have been built
+ * from the same header.  A caller that may meet a newer library calls rt_scene_options_init_sized(&o, sizeof o) instead: only
+ * that many bytes are written, struct_size is set to it, and rt_scene_create_ex treats the fields beyond it as default. */
 void rt_scene_options_init(rt_scene_options *options);
+int rt_scene_options_init_sized(rt_scene_options *options, uint32_t struct_size);
 int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_options *options /* NULL: defaults */,
                        rt_scene **out_scene);
 

@@ -91,8 +91,7 @@ int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options
  * whose box a ray could enter), out[5] records on the longest chain. */
 int rt_debug_wide_layout(const rt_scene_desc *desc, const rt_scene_options *options, uint64_t out[6]);
 
-/* Which kernel the calling thread's last render launched: out[0] = path slots of the pool kernel (0: path_kernel rendered —
- * also when the pool kernel was asked for and the scene did not qualify), out[1] = LDS level, out[2] = workgroup threads,
+/* How the calling thread's last render was launched: out[0] = 0 (reserved), out[1] = LDS level, out[2] = workgroup threads,
  * out[3] = workgroups. */
 int rt_debug_last_launch(uint32_t out[4]);
 

@@ -169,7 +169,7 @@ class SceneCreateOptions(C.Structure):
     """rt_scene_options (per-scene options of rt_scene_create_ex)."""
     _fields_ = [("struct_size", C.c_uint32), ("walk", C.c_int32), ("leaf_max", C.c_int32), ("refit", C.c_int32),
                 ("use_lds", C.c_int32), ("th_prim", C.c_int32), ("th_other", C.c_int32), ("th_shade", C.c_int32),
-                ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("pool", C.c_int32),
+                ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("reserved_pool", C.c_int32),
                 ("flat_max", C.c_int32), ("start_shortcut", C.c_int32), ("defer_instances", C.c_int32),
                 ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("wide", C.c_int32)]
 
@@ -210,6 +210,7 @@ RT_AMD_SYMBOLS = {
     "rt_tiles_to_frame_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_resolve_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_scene_options_init": (None, [C.c_void_p]),
+    "rt_scene_options_init_sized": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_scene_create_ex": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_resolve_rgb8_values_device": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_tiles_to_frame_rgb8_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -317,10 +318,10 @@ def debug_wide_layout(host_scene, **option_fields) -> dict:
 
 
 def debug_last_launch() -> dict:
-    """rt_debug_last_launch: which kernel this thread's last render ran (pool_slots 0: path_kernel)."""
+    """rt_debug_last_launch: how this thread's last render was launched (LDS level, workgroup threads, workgroups)."""
     buf = (C.c_uint32 * 4)()
     _check(amd_lib().rt_debug_last_launch(buf), "rt_debug_last_launch")
-    return {"pool_slots": int(buf[0]), "lds_level": int(buf[1]), "threads": int(buf[2]), "grid": int(buf[3])}
+    return {"lds_level": int(buf[1]), "threads": int(buf[2]), "grid": int(buf[3])}
 
 
 def debug_stage_profile() -> dict:

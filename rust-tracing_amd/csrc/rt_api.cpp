@@ -26,8 +26,6 @@ Tuning::Tuning() {
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
     env("RT_WIDE", wide);
-    env("RT_POOL", pool); env("RT_POOL_PROF", pool_prof); env("RT_POOL_AUX", pool_aux); env("RT_POOL_WANT_WORDS", pool_want_words); env("RT_POOL_SERVICE", pool_service); env("RT_POOL_TH_PRIM", pool_th[0]); env("RT_POOL_TH_OTHER", pool_th[1]);
-    env("RT_POOL_TH_X", pool_th[2]); env("RT_POOL_TH_BOX", pool_th[3]); env("RT_POOL_PATIENCE", pool_patience); env("RT_POOL_FULL", pool_full);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_FLAT_MAX")) ordered_options.flat_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
@@ -171,7 +169,6 @@ Tuning effective_tuning(const rt_scene *scene) {
     for (int k = 0; k < 5; ++k)
         if (th[k] >= 0 && tn.forced[k] < 0) tn.forced[k] = th[k];
     if (o.sample_buffer_bytes > 0) tn.sample_buffer_bytes = (size_t)o.sample_buffer_bytes;
-    if (o.pool >= 0) tn.pool = o.pool;
     if (o.start_shortcut >= 0) tn.start_shortcut = o.start_shortcut;
     if (o.defer_instances >= 0) tn.defer = o.defer_instances;
     if (o.seq_lookahead >= 0) tn.seq_lookahead = o.seq_lookahead;
@@ -214,52 +211,15 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     const int lds = tn.use_lds != 0 ? scene->lds_level : 0;
     const int threads = block_threads(scene, lds);
     const int bpc = scene->blocks_per_cu[lds][counted ? 1 : 0];
-    size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
-    // The pool kernel (rt_pool_kernel.hip: paths move between traversal lanes and full-width shading rounds through an LDS pool)
-    // renders ordered scenes that live in the LDS whole, if what the scene leaves of the LDS holds a pool worth having.
-    uint32_t pool_slots = 0, pool_off = 0;
-    bool pool_aux = aux_in_lds(scene, lds);
-    uint32_t pool_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
-    if (!counted && tn.pool != 0 && scene->ordered && !scene->wide && lds == 3 && p.max_depth < 65536 && tn.pool_service >= 1 && tn.pool_service * 64 < threads) {
-        // the pool takes what the scene, the stacks and the sequence leave; the small tables stay in the LDS only if the pool
-        // still gets POOL_WANT_WORDS words (a pool much smaller than the number of walking lanes starves them)
-        auto layout = [&](bool with_aux, uint32_t &world_off) {
-            const size_t a_end = aux_offset(scene, lds) + (with_aux ? scene->aux_bytes : 0u);
-            const bool world = scene->has_instances && align16(a_end) + world_bytes(scene, lds) + pool_ctl_bytes() + 4 * 64 * POOL_SLOT_BYTES <= LDS_BUDGET_BYTES;
-            world_off = world ? (uint32_t)align16(a_end) : 0xffffffffu;
-            return align16(align16(a_end) + (world ? world_bytes(scene, lds) : 0u));
-        };
-        auto words_at = [&](size_t off) {
-            const size_t room = LDS_BUDGET_BYTES > off + pool_ctl_bytes() ? LDS_BUDGET_BYTES - off - pool_ctl_bytes() : 0;
-            const size_t wds = room / (POOL_SLOT_BYTES * 64);
-            return wds > 16 ? (size_t)16 : wds;
-        };
-        uint32_t w_off = 0xffffffffu;
-        size_t off = layout(pool_aux, w_off), words = words_at(off);
-        if (pool_aux && (tn.pool_aux == 0 || (tn.pool_aux < 0 && words < (size_t)tn.pool_want_words))) {
-            uint32_t w_off2 = 0xffffffffu;
-            const size_t off2 = layout(false, w_off2), words2 = words_at(off2);
-            if (words2 > words) { pool_aux = false; off = off2; words = words2; w_off = w_off2; }
-        }
-        if (words >= 4 && words * 64 + (size_t)threads < 65536) {
-            pool_off = (uint32_t)off;
-            pool_slots = (uint32_t)(words * 64);
-            pool_world_off = w_off;
-            dyn_lds = pool_off + pool_ctl_bytes() + (size_t)pool_slots * POOL_SLOT_BYTES;
-        } else {
-            pool_aux = aux_in_lds(scene, lds);
-        }
-    }
-    const bool pooled = pool_slots != 0;
+    const size_t dyn_lds = dynamic_lds_bytes(scene, lds, counted);
     // persistent grid: every resident wave pulls jobs until none are left
-    int64_t grid = (int64_t)scene->n_cus * (pooled ? 1 : bpc);
-    const int64_t waves_per_block = pooled ? tn.pool_service : threads / 64; // (waves that hand out jobs)
+    int64_t grid = (int64_t)scene->n_cus * bpc;
+    const int64_t waves_per_block = threads / 64;
     // (a small frame gets a smaller grid: a wave with fewer than MIN_JOBS_PER_WAVE jobs costs more to start than it adds)
     const int64_t max_useful = (n_local * 64 * chunk + MIN_JOBS_PER_WAVE * waves_per_block - 1) / (MIN_JOBS_PER_WAVE * waves_per_block);
     if (grid > max_useful) grid = max_useful;
     if (grid < 1) grid = 1;
-    // (pool kernel: the attenuation stack has one column per path id: slots + threads of every workgroup)
-    const uint32_t n_threads = (uint32_t)(grid * (threads + (int64_t)pool_slots));
+    const uint32_t n_threads = (uint32_t)(grid * threads);
 
     // The scratch of this (scene, stream).  The entry is taken — and marked in use — under the scene's lock; the launches are
     // enqueued outside it on a copy of the handles.  Only entries nobody holds are ever evicted, after waiting for the event their
@@ -274,7 +234,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             if (it != scene->workspaces.end() && it->second.in_use > 0) it->second.in_use--;
         }
     } release{scene, stream};
-    const bool colours = scene->parks_colours || pooled; // (the pool kernel parks every attenuation as a colour)
+    const bool colours = scene->parks_colours;
     {
         std::lock_guard<std::mutex> lock(scene->mu);
         if (scene->workspaces.find(stream) == scene->workspaces.end() && scene->workspaces.size() >= MAX_WORKSPACES) {
@@ -358,25 +318,21 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
                 }
                 x.sample_bytes = need_samples;
             }
-            if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, 2 * sizeof(uint32_t))); // [1]: the pool kernel's give-up flag
+            if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, sizeof(uint32_t)));
         }
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
         w.in_use++;
         release.armed = true;
         ws = w;
     }
-    if (counted || (pooled && tn.pool_prof != 0)) {
-        if (!counted) HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemsetAsync(ws.counters, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
-        if (!counted) HIP_TRY(hipStreamSynchronize(stream));
-    }
+    if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
 
     KParams K{};
     K.nodes = scene->nodes.ptr; K.spheres = scene->spheres.ptr; K.quads = scene->quads.ptr; K.insts = scene->insts.ptr;
     K.media = scene->media.ptr; K.mats = scene->mats.ptr; K.texs = scene->texs.ptr; K.perlins = scene->perlins.ptr;
     K.images = scene->images.ptr; K.texels = scene->texels.ptr; K.srgb_lut = scene->lut.ptr;
     K.out = d_out;
-    K.counters = (counted || (pooled && tn.pool_prof != 0)) ? ws.counters : nullptr;
+    K.counters = counted ? ws.counters : nullptr;
     K.cam = *camera;
     K.seed_mixed = host_mix64(p.seed + 0x9E3779B97F4A7C15ull);
     K.n_nodes = scene->n_nodes;
@@ -391,7 +347,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
-    K.lds_world_off = pool_world_off;
+    K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
     K.slow_min = (uint32_t)tn.slow_min; K.slow_age = (uint32_t)tn.slow_age;
@@ -412,11 +368,6 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
     // (a lane keeps the instances it has yet to walk as one 32-bit mask of their indices)
     K.defer_instances = (scene->ordered && tn.defer != 0 && scene->insts.bytes / sizeof(Instance) <= 32u) ? 1u : 0u;
-    if (pooled) { // (the pool kernel's thresholds are lane counts)
-        K.pool_off = pool_off; K.pool_slots = pool_slots; K.pool_service_waves = (uint32_t)tn.pool_service;
-        K.pool_patience = (uint32_t)tn.pool_patience; K.pool_full = (uint32_t)tn.pool_full;
-        K.th_prim = (uint32_t)tn.pool_th[0]; K.th_other = (uint32_t)tn.pool_th[1]; K.th_shade = (uint32_t)tn.pool_th[2]; K.th_box = (uint32_t)tn.pool_th[3];
-    }
 
     // Launch k renders samples [sb, sb + ns) into its scratch set's sample buffer; sum_samples_kernel then adds them onto `out`
     // in sample order.  Pipelined: launch k runs on internal stream k % 2; its summation waits for launch k - 1's (the sums
@@ -450,12 +401,11 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             K.grab_taper = tn.grab_taper > 0 ? 1.0f / (float)(waves * tn.grab_taper) : 1.0f; // (default 8, tools/sweep_grabs.sh)
         }
         K.accumulate = (p.accumulate || sb > p.sample_begin) ? 1 : 0;
-        HIP_TRY(hipMemsetAsync(x.job_counter, 0, pooled ? 2 * sizeof(uint32_t) : sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(x.job_counter, 0, sizeof(uint32_t), s));
         {
             void *args[] = {(void *)&K};
             const uint32_t kf = kernel_features_for(scene->features, lds, scene->ordered);
-            const void *fn = pooled ? pool_kernel_for(kf, pool_aux, tn.pool_prof != 0) : path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds), scene->wide);
-            if (pooled && dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+            const void *fn = path_kernel_for(lds, counted, kf, scene->ordered, aux_in_lds(scene, lds), scene->wide);
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(threads), args, dyn_lds, s));
         }
         HIP_TRY(hipGetLastError());
@@ -466,28 +416,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
     HIP_TRY(hipEventRecord(ws.ev_done, stream));
-    g_last_launch[0] = pool_slots; g_last_launch[1] = (uint32_t)lds; g_last_launch[2] = (uint32_t)threads; g_last_launch[3] = (uint32_t)grid;
-    if (pooled && tn.pool_prof != 0) { // RT_POOL_PROF=1: where the pool kernel's waves spent their cycles (stderr)
-        HIP_TRY(hipStreamSynchronize(stream));
-        unsigned long long c[30];
-        HIP_TRY(hipMemcpy(c, ws.counters, sizeof c, hipMemcpyDeviceToHost));
-        static const char *names[10] = {"box", "sphere", "quad", "other", "exchange", "exchange-none", "idle", "svc-shade", "svc-end", "svc-poll"};
-        unsigned long long total = 0;
-        for (int q = 0; q < 10; ++q) total += c[q * 3];
-        fprintf(stderr, "pool profile (%u slots, %d service waves):\n", pool_slots, tn.pool_service);
-        for (int q = 0; q < 10; ++q)
-            if (c[q * 3 + 1]) fprintf(stderr, "  %-14s cycles %5.1f %%  rounds %10llu  lanes/round %5.1f  cycles/round %8.1f\n", names[q], 100.0 * (double)c[q * 3] / (double)total,
-                    c[q * 3 + 1], (double)c[q * 3 + 2] / (double)c[q * 3 + 1], (double)c[q * 3] / (double)c[q * 3 + 1]);
-    }
-    if (pooled) { // a pool-kernel launch that stopped itself (idle watchdog, slot sanity checks) left an incomplete frame: always an error
-        // (the pool kernel is an opt-in experiment: the wait this costs is its own)
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (int h = 0; h < (pipelined ? 2 : 1); ++h) {
-            uint32_t flag = 0;
-            HIP_TRY(hipMemcpy(&flag, ws.half[h].job_counter + 1, sizeof flag, hipMemcpyDeviceToHost));
-            if (flag) return fail(RT_ERR_HIP, "rt_render: the pool kernel stopped itself (flag " + std::to_string(flag) + ")");
-        }
-    }
+    g_last_launch[0] = 0u; g_last_launch[1] = (uint32_t)lds; g_last_launch[2] = (uint32_t)threads; g_last_launch[3] = (uint32_t)grid;
 
     if (counted) {
         unsigned long long host[COUNTER_WORDS];
@@ -506,6 +435,22 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
 }
 
 } // namespace
+
+namespace rtapi {
+int resolve_scene_options(const rt_scene_options *options, rt_scene_options &opt, const char *who) {
+    rt_scene_options_init(&opt);
+    if (options) {
+        const uint32_t size = options->struct_size;
+        if (size < 8 || size > sizeof opt || size % 4 != 0) return fail(RT_ERR_INVALID_ARGUMENT, std::string(who) + ": rt_scene_options.struct_size is not one this library knows");
+        memcpy(&opt, options, size); // (an older, shorter struct: the fields it lacks keep their defaults)
+        opt.struct_size = (uint32_t)sizeof opt;
+        // the 56-byte struct of round 2 ended in a reserved word that its init zeroed, where flat_max (0: off) now is
+        if (size <= 56) opt.flat_max = -1;
+    }
+    if (opt.walk < RT_WALK_DEFAULT || opt.walk > RT_WALK_OWN_TREES) return fail(RT_ERR_INVALID_ARGUMENT, std::string(who) + ": unknown walk");
+    return RT_OK;
+}
+} // namespace rtapi
 
 extern "C" {
 
@@ -542,8 +487,20 @@ void rt_scene_options_init(rt_scene_options *o) {
     o->walk = RT_WALK_DEFAULT; o->leaf_max = 0; o->refit = -1; o->use_lds = -1;
     o->th_prim = o->th_other = o->th_shade = o->th_box = o->th_new = -1;
     o->sample_buffer_bytes = 0;
-    o->pool = -1;
+    o->reserved_pool = -1;
     o->flat_max = o->start_shortcut = o->defer_instances = o->seq_lookahead = o->slow_min = o->slow_age = o->wide = -1;
+}
+
+// (for a caller compiled against an older, shorter struct: nothing beyond ITS size is written)
+int rt_scene_options_init_sized(rt_scene_options *o, uint32_t struct_size) {
+    if (!o) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_options_init_sized: null argument");
+    if (struct_size < 8 || struct_size > sizeof(rt_scene_options) || struct_size % 4 != 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_options_init_sized: struct_size is not one this library knows");
+    rt_scene_options full;
+    rt_scene_options_init(&full);
+    full.struct_size = struct_size;
+    memcpy(o, &full, struct_size);
+    return RT_OK;
 }
 
 int rt_scene_create(const rt_scene_desc *desc, int device, rt_scene **out_scene) { return rt_scene_create_ex(desc, device, nullptr, out_scene); }
@@ -552,13 +509,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     if (!desc || !out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create: null argument");
     *out_scene = nullptr;
     rt_scene_options opt;
-    rt_scene_options_init(&opt);
-    if (options) {
-        if (options->struct_size < 8 || options->struct_size > sizeof opt) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create_ex: rt_scene_options.struct_size is not one this library knows");
-        memcpy(&opt, options, options->struct_size); // (an older, shorter struct: the fields it lacks keep their defaults)
-        opt.struct_size = (uint32_t)sizeof opt;
-    }
-    if (opt.walk < RT_WALK_DEFAULT || opt.walk > RT_WALK_OWN_TREES) return fail(RT_ERR_INVALID_ARGUMENT, "rt_scene_create_ex: unknown walk");
+    if (int orc = resolve_scene_options(options, opt, "rt_scene_create_ex")) return orc;
     // the process defaults in force now (RT_* variables, rt_debug_set_*), then the caller's options
     const Tuning tn = tuning_snapshot();
     const int walk = opt.walk != RT_WALK_DEFAULT ? opt.walk : tn.ordered;
@@ -566,8 +517,7 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     OrderedOptions oopt = tn.ordered_options;
     if (opt.leaf_max > 0) oopt.leaf_max = (uint32_t)opt.leaf_max < OREF_MAX_LEAF ? (uint32_t)opt.leaf_max : OREF_MAX_LEAF;
     if (opt.flat_max >= 0) oopt.flat_max = (uint32_t)opt.flat_max;
-    const bool wants_pool = opt.pool >= 0 ? opt.pool != 0 : tn.pool != 0; // (the pool kernel walks two-child records only)
-    const int want_wide = wants_pool ? 0 : (opt.wide >= 0 ? opt.wide : tn.wide); // (-1: where it measured faster, below)
+    const int want_wide = opt.wide >= 0 ? opt.wide : tn.wide; // (-1: where it measured faster, below)
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, refit);

@@ -17,7 +17,7 @@ namespace rtapi {
 using namespace rtd;
 using namespace rtk;
 
-extern thread_local uint32_t g_last_launch[4]; // of the calling thread's last render: pool slots (0: path_kernel), LDS level, workgroup threads, grid
+extern thread_local uint32_t g_last_launch[4]; // of the calling thread's last render: 0 (reserved), LDS level, workgroup threads, grid
 int fail(int status, const std::string &msg); // sets rt_last_error() of the calling thread, returns `status`
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -74,12 +74,6 @@ struct Tuning {
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     int wide = -1;         // own trees with four-child records (rt_layout.h ONode4): 1 always, 0 never, -1 for scenes of 64 primitives or more (RT_WIDE)
-    int pool = 0;          // 1: ordered LDS-resident scenes render with the pool kernel (ray compaction across stages; RT_POOL)
-    int pool_prof = 0;     // ... 1: the instrumented variant; prints a per-section cycle profile to stderr after every render (RT_POOL_PROF)
-    int pool_aux = -1, pool_want_words = 8; // ... small tables in the LDS too: 1 yes, 0 no, -1 only if the pool still gets this many words
-    int pool_service = 2;  // ... service waves per workgroup (RT_POOL_SERVICE)
-    int pool_th[4] = {8, 12, 16, 16}; // ... lanes that must wait for a primitive test / frame-or-sequence step / exchange; box loop floor (RT_POOL_TH_*)
-    int pool_patience = 2, pool_full = 64; // ... idle polls before a service wave takes a partial word; entries that make a word 'full'
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
     int slow_min = 4, slow_age = 32; // KParams::slow_min / slow_age (RT_SLOW_MIN, RT_SLOW_AGE; slow_min 1: nobody waits)
     int seq_lookahead = 1;  // scenes with media: a query looks ahead at the boxes of the sequence's later steps when it starts (RT_SEQ_LOOKAHEAD)
@@ -99,6 +93,11 @@ struct Tuning {
         return t;
     }
 };
+// The caller's rt_scene_options (any struct_size this library has ever shipped, or null) laid over the defaults: every field at or
+// beyond the caller's struct_size is the default; RT_ERR_INVALID_ARGUMENT for a size or a walk nobody knows.  One helper for
+// rt_scene_create_ex and the layout hooks of rt_debug.cpp, so that what a test inspects is what a scene gets.
+int resolve_scene_options(const rt_scene_options *options, rt_scene_options &out, const char *who);
+// the tree-building options a scene gets from them (on top of the process defaults)
 // Process-wide defaults (RT_* environment variables, rt_debug_set_*): read and written under one mutex; a scene takes its
 // copy when it is created (walk, refit, tree options) and every launch takes one (thresholds, LDS use).
 Tuning tuning_snapshot();

@@ -48,14 +48,14 @@ int rt_debug_ordered_layout(const rt_scene_desc *desc, rt_debug_ordered *io) { r
 
 int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options *options, rt_debug_ordered *io) {
     if (!desc || !io) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_ordered_layout: null argument");
+    rt_scene_options opt; // (checked and defaulted exactly as rt_scene_create_ex does)
+    if (int orc = resolve_scene_options(options, opt, "rt_debug_ordered_layout_ex")) return orc;
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, true);
         OrderedOptions oopt = tuning_snapshot().ordered_options;
-        if (options && options->struct_size >= sizeof(rt_scene_options)) {
-            if (options->leaf_max > 0) oopt.leaf_max = (uint32_t)options->leaf_max < OREF_MAX_LEAF ? (uint32_t)options->leaf_max : OREF_MAX_LEAF;
-            if (options->flat_max >= 0) oopt.flat_max = (uint32_t)options->flat_max;
-        }
+        if (opt.leaf_max > 0) oopt.leaf_max = (uint32_t)opt.leaf_max < OREF_MAX_LEAF ? (uint32_t)opt.leaf_max : OREF_MAX_LEAF;
+        if (opt.flat_max >= 0) oopt.flat_max = (uint32_t)opt.flat_max;
         build_ordered(cs, oopt);
     } catch (const CompileError &e) {
         return fail(e.status, e.what());
@@ -117,14 +117,14 @@ int rt_debug_ordered_layout_ex(const rt_scene_desc *desc, const rt_scene_options
 //   out[5] deepest chain of records
 int rt_debug_wide_layout(const rt_scene_desc *desc, const rt_scene_options *options, uint64_t out[6]) {
     if (!desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_wide_layout: null argument");
+    rt_scene_options opt;
+    if (int orc = resolve_scene_options(options, opt, "rt_debug_wide_layout")) return orc;
     CompiledScene cs;
     try {
         cs = compile_scene(*desc, true);
         OrderedOptions oopt = tuning_snapshot().ordered_options;
-        if (options && options->struct_size >= sizeof(rt_scene_options)) {
-            if (options->leaf_max > 0) oopt.leaf_max = (uint32_t)options->leaf_max < OREF_MAX_LEAF ? (uint32_t)options->leaf_max : OREF_MAX_LEAF;
-            if (options->flat_max >= 0) oopt.flat_max = (uint32_t)options->flat_max;
-        }
+        if (opt.leaf_max > 0) oopt.leaf_max = (uint32_t)opt.leaf_max < OREF_MAX_LEAF ? (uint32_t)opt.leaf_max : OREF_MAX_LEAF;
+        if (opt.flat_max >= 0) oopt.flat_max = (uint32_t)opt.flat_max;
         oopt.wide = true;
         build_ordered(cs, oopt);
     } catch (const CompileError &e) {

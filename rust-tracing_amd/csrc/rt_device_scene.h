@@ -1,6 +1,5 @@
-// rt_device_scene.h — device-side pieces shared by the two render kernels (rt_kernel.hip: lanes own paths; rt_pool_kernel.hip:
-// paths move between traversal lanes and shading rounds through an LDS pool): frame changes, textures and Perlin noise, record
-// loads, the conservative f32 box tests.  Everything is file-local (anonymous namespace) in each translation unit.
+// rt_device_scene.h — device-side pieces of the render kernel (rt_kernel.hip): frame changes, textures and Perlin noise, record
+// loads, the conservative f32 box and quad tests.  Everything is file-local (anonymous namespace).
 #pragma once
 #include "rt_kernels.h"
 #include "rt_amd_debug.h"

@@ -38,8 +38,7 @@ struct KParams {
     const double *srgb_lut;
     double *out;
     double *samples;                // [local tile][sample of this launch][64 pixels][3]: one colour per camera path
-    double *att_stack;              // [max_depth + 1][3][n_threads]: parked attenuations that are a texture's value (path_kernel); the pool
-                                    // kernel parks every attenuation here, as [max_depth + 1][n_threads][3]
+    double *att_stack;              // [max_depth + 1][3][n_threads]: parked attenuations that are a texture's value
     uint32_t *att_ids;              // [max_depth + 1 - 8][n_threads]: parked material indices that no longer fit the lane's registers
     uint32_t ids_ok;                // 1: material indices fit 16 bits (else every attenuation is parked as a colour, by a kernel with textures)
     uint32_t id_one;                // index of the material table's extra last entry, whose albedo is Color::ONE
@@ -85,11 +84,6 @@ struct KParams {
     uint32_t lds_stack_off;
     uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)
     uint32_t lds_prof_off;          // COUNT kernels: per-wave profile rows (last)
-    // pool kernel (rt_pool_kernel.hip): the path-slot pool in the LDS and the split of the workgroup's waves
-    uint32_t pool_off, pool_slots;  // control block + slots (a multiple of 64)
-    uint32_t pool_service_waves;    // the first so many waves shade and end paths, the others walk
-    uint32_t pool_patience;         // idle polls after which a service wave takes a word that is not full
-    uint32_t pool_full;             // entries a word must hold to be taken at once
 };
 
 // What a scene can contain.  A kernel instantiated without a feature has that code compiled out, which matters for
@@ -144,9 +138,6 @@ constexpr uint32_t FEAT_SPHERES_QUADS_TEXTURES = F_SPHERES | F_QUADS | F_TEXTURE
 uint32_t kernel_features_for(uint32_t scene_features, int lds, bool ordered);
 int kernel_threads_for(uint32_t kernel_features, int lds, bool ordered); // workgroup size of that instantiation
 const void *path_kernel_for(int lds, bool counted, uint32_t feat, bool ordered, bool aux, bool wide);
-const void *pool_kernel_for(uint32_t feat, bool aux, bool prof); // ordered, LDS-resident scenes (lds level 3)
-size_t pool_ctl_bytes();
-constexpr size_t POOL_SLOT_BYTES = 96;
 
 // launches of the small kernels (all asynchronous on `stream`; errors through hipGetLastError)
 void launch_sum_samples(const KParams &K, unsigned grid, hipStream_t stream);

@@ -69,17 +69,47 @@ def test_scene_options_are_checked_before_anything_else(rt):
     needed to find out); a shorter struct of an older caller is accepted."""
     lib = rt.amd_lib()
     o = rt.scene_options()
-    assert (o.struct_size, o.walk, o.refit, o.use_lds, o.th_prim, o.sample_buffer_bytes, o.pool) == (C.sizeof(rt.SceneCreateOptions), -1, -1, -1, -1, 0, -1)
+    assert (o.struct_size, o.walk, o.refit, o.use_lds, o.th_prim, o.sample_buffer_bytes, o.reserved_pool) == (C.sizeof(rt.SceneCreateOptions), -1, -1, -1, -1, 0, -1)
     hs = rt.HostScene(4, width=16, spp=1)
     handle = C.c_void_p()
     for bad in (dict(struct_size=4), dict(struct_size=4096), dict(walk=7)):
         opts = rt.scene_options(**bad)
         assert lib.rt_scene_create_ex(C.byref(hs.desc), 0, C.byref(opts), C.byref(handle)) == -1, bad  # RT_ERR_INVALID_ARGUMENT
-    older = rt.scene_options(struct_size=48, walk=rt.RT_WALK_REFERENCE_ORDER)  # (the struct as it was before `pool` was added)
+    older = rt.scene_options(struct_size=48, walk=rt.RT_WALK_REFERENCE_ORDER)  # (the struct as it was in round 1)
     rc = lib.rt_scene_create_ex(C.byref(hs.desc), 0, C.byref(older), C.byref(handle))
     assert rc == (0 if lib.rt_device_count() > 0 else -2)
     if rc == 0:
         lib.rt_scene_destroy(handle)
+
+
+def test_an_older_callers_shorter_options_struct_keeps_the_defaults_it_never_knew(rt):
+    """Round 2's rt_scene_options was 56 bytes and ended in a reserved word that its init zeroed — where flat_max (0: off) is
+    now.  A caller built against it must get the default flat leaves (Cornell: 4 records, not 17), and the sized init must
+    not write past the caller's struct."""
+    lib = rt.amd_lib()
+    hs = rt.HostScene(6, width=16, spp=1)
+
+    def layout(opts):
+        io = rt.DebugOrdered()
+        assert lib.rt_debug_ordered_layout_ex(C.addressof(hs.desc), C.addressof(opts) if opts is not None else None, C.addressof(io)) == 0, lib.rt_last_error()
+        return int(io.n_nodes)
+
+    default_records = layout(None)
+    old = rt.scene_options()
+    C.memset(C.addressof(old), 0xAB, C.sizeof(old))
+    assert lib.rt_scene_options_init_sized(C.addressof(old), 56) == 0
+    raw = bytes(old)
+    assert raw[56:] == b"\xab" * (C.sizeof(old) - 56), "the sized init wrote past the caller's 56 bytes"
+    assert old.struct_size == 56
+    C.memset(C.addressof(old) + 52, 0, 4)  # what round 2's own init left in its reserved word
+    assert layout(old) == default_records
+    off = rt.scene_options(flat_max=0)
+    assert layout(off) > default_records  # (the switch itself still works for a caller that knows it)
+    for bad in (4, 58, 4096):
+        assert lib.rt_scene_options_init_sized(C.addressof(old), bad) == -1
+    short = rt.scene_options(struct_size=4)
+    io = rt.DebugOrdered()
+    assert lib.rt_debug_ordered_layout_ex(C.addressof(hs.desc), C.addressof(short), C.addressof(io)) == -1
 
 
 def test_ctypes_structs_match_the_c_layout(rt, tmp_path):
