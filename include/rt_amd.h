@@ -286,6 +286,9 @@ typedef struct rt_scene_options {
                                     rounds (slow_min 1: nobody waits) */
     int32_t wide;                /* own trees: 1: records of four children, 0: of two; -1: default — four for scenes of 64 primitives or
                                     more (DESIGN.md "Wide records") */
+    int32_t quad_filter;         /* -1 default (on); 0: every quad of a multi-quad leaf gets the exact test at once, without the conservative
+                                    f32 filter in front of it (DESIGN.md "Quad filter") */
+    int32_t reserved_tail;       /* ignored */
 } rt_scene_options;
 /* Fills the defaults.  rt_scene_options_init writes sizeof(rt_scene_options) of THIS header: caller and library must have been built
  * from the same header.  A caller that may meet a newer library calls rt_scene_options_init_sized(&o, sizeof o) instead: only

@@ -31,6 +31,14 @@ int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, doubl
 int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, double tmin, double tmax,
                        uint8_t *out_exact_hit, uint8_t *out_f32_hit, int device);
 
+/* Test hook: the quad stage's conservative f32 filter (rt_device_scene.h quad_pair_keep) and the exact f64 Quad::hit
+ * (src/quad.rs:96-127) on n (ray, quad) pairs — rays[i] = (origin xyz, direction xyz), quads[i] = (Q xyz, u xyz, v xyz), the
+ * derived fields as Quad::new computes them (src/quad.rs:24-27), interval [tmin, tmax].  out_exact_hit[i] = 1: the exact test
+ * accepts; out_keep[i] bit 0 / bit 1: the filter keeps the quad in the first / second slot of its pair record.  The filter must
+ * keep whatever the exact test accepts (tests/test_gpu_parity.py). */
+int rt_debug_quad_filter_tests(int64_t n, const double *rays, const double *quads, double tmin, double tmax, uint8_t *out_exact_hit,
+                               uint8_t *out_keep, int device);
+
 /* Test hook (no GPU needed): runs the scene compiler and returns the records the device would walk — the f64 box each
  * carries after refitting (refit != 0) or as the reference has it (refit == 0), the outward-rounded f32 box actually
  * tested, the threaded links, and the bound of the record's own primitives — so that tests can check the compiler's

@@ -171,7 +171,8 @@ class SceneCreateOptions(C.Structure):
                 ("use_lds", C.c_int32), ("th_prim", C.c_int32), ("th_other", C.c_int32), ("th_shade", C.c_int32),
                 ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("reserved_pool", C.c_int32),
                 ("flat_max", C.c_int32), ("start_shortcut", C.c_int32), ("defer_instances", C.c_int32),
-                ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("wide", C.c_int32)]
+                ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("wide", C.c_int32),
+                ("quad_filter", C.c_int32), ("reserved_tail", C.c_int32)]
 
 
 def scene_options(**kw) -> "SceneCreateOptions":
@@ -235,6 +236,8 @@ RT_AMD_DEBUG_SYMBOLS = {
                                 C.POINTER(C.c_double), C.c_int]),
     "rt_debug_box_tests": (C.c_int, [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                      C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int]),
+    "rt_debug_quad_filter_tests": (C.c_int, [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                                             C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int]),
     "rt_debug_compiled_nodes": (C.c_int, [C.POINTER(SceneDesc), C.c_int32, C.POINTER(DebugNode), C.c_int64,
                                           C.POINTER(C.c_int64)]),
     "rt_debug_stage_profile": (C.c_int, [C.POINTER(C.c_uint64)]),
@@ -266,6 +269,22 @@ def debug_box_tests(rays, boxes, tmin, tmax, device=0):
                                         device), "rt_debug_box_tests")
     assert (((f32 >> 1) & 1) == ((f32 >> 2) & 1)).all(), "the two slots of the pair test disagree on the same box"
     return exact.astype(bool), (f32 & 1).astype(bool), ((f32 >> 1) & 1).astype(bool)
+
+
+def debug_quad_filter_tests(rays, quads, tmin, tmax, device=0):
+    """rt_debug_quad_filter_tests: per (ray, quad = Q, u, v) pair: does the exact f64 Quad::hit accept within [tmin, tmax]? does the
+    quad stage's conservative f32 filter keep the quad (both slots of the pair record must agree)?"""
+    import numpy as np
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    quads = np.ascontiguousarray(quads, dtype=np.float64).reshape(-1, 9)
+    n = rays.shape[0]
+    assert quads.shape[0] == n
+    exact = np.zeros(n, dtype=np.uint8); keep = np.zeros(n, dtype=np.uint8)
+    _check(amd_lib().rt_debug_quad_filter_tests(n, rays.ctypes.data_as(C.POINTER(C.c_double)), quads.ctypes.data_as(C.POINTER(C.c_double)),
+                                                tmin, tmax, exact.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                keep.ctypes.data_as(C.POINTER(C.c_uint8)), device), "rt_debug_quad_filter_tests")
+    assert ((keep & 1) == ((keep >> 1) & 1)).all(), "the two slots of the pair record disagree on the same quad"
+    return exact.astype(bool), (keep & 1).astype(bool)
 
 
 def debug_compiled_nodes(host_scene, refit=True):

@@ -1,6 +1,7 @@
 // rt_api.cpp — the host side of librt_amd: the C ABI of include/rt_amd.h (scene upload, render launches, frame-end
 // helpers).  Plain C++ over the HIP runtime API; the kernels live in rt_kernel.hip and are reached through rt_kernels.h.
 #include "rt_api.hpp"
+#include "rt_qfilt.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -25,7 +26,7 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
-    env("RT_WIDE", wide);
+    env("RT_WIDE", wide); env("RT_QUAD_FILTER", quad_filter);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_FLAT_MAX")) ordered_options.flat_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
@@ -174,6 +175,7 @@ Tuning effective_tuning(const rt_scene *scene) {
     if (o.seq_lookahead >= 0) tn.seq_lookahead = o.seq_lookahead;
     if (o.slow_min >= 1) tn.slow_min = o.slow_min;
     if (o.slow_age >= 0) tn.slow_age = o.slow_age;
+    if (o.quad_filter >= 0) tn.quad_filter = o.quad_filter;
     return tn;
 }
 
@@ -347,6 +349,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_image = scene->lds_image.ptr; K.lds_image_bytes = lds_image_bytes_for(scene, lds);
     K.lds_off_node_b = scene->lds_off_node_b;
     K.lds_off_spheres = scene->lds_off_spheres; K.lds_off_quads = scene->lds_off_quads;
+    K.lds_off_qfilt = (lds == 3 && tn.quad_filter != 0 && scene->lds_off_qfilt != 0) ? scene->lds_off_qfilt : 0xffffffffu;
     K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
@@ -489,6 +492,7 @@ void rt_scene_options_init(rt_scene_options *o) {
     o->sample_buffer_bytes = 0;
     o->reserved_pool = -1;
     o->flat_max = o->start_shortcut = o->defer_instances = o->seq_lookahead = o->slow_min = o->slow_age = o->wide = -1;
+    o->quad_filter = -1;
 }
 
 // (for a caller compiled against an older, shorter struct: nothing beyond ITS size is written)
@@ -667,11 +671,22 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
         }
         s->lds_off_node_b = (uint32_t)off_b;
         const size_t off_quads = off_sph + cs.spheres.size() * sizeof(Sphere);
-        const size_t total = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
+        // behind the quads: their f32 filter records (rt_qfilt.hpp) — if some leaf of the library's own trees holds more than one quad
+        // (a single quad's exact test runs in its round anyway) and the LDS has room for them
+        bool flat_quads = false;
+        if (cs.ordered) {
+            auto multi = [](uint32_t ref) { return (ref >> OREF_KIND_SHIFT) == OK_QUADS && ((ref >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) != 0u; };
+            for (const ONode &nd : cs.onodes) flat_quads = flat_quads || multi(nd.c[0]) || multi(nd.c[1]);
+            for (const ONode4 &nd : cs.onodes4) for (int k = 0; k < 4; ++k) flat_quads = flat_quads || multi(nd.c[k]);
+        }
+        const size_t off_qfilt = (off_quads + cs.quads.size() * sizeof(Quad) + 15u) & ~(size_t)15u;
+        const size_t total_plain = off_qfilt, total_filt = off_qfilt + cs.quads.size() * sizeof(QFiltPair);
         const size_t stack3 = stack_bytes(s, 3), stack1 = stack_bytes(s, 1); // (the two levels' kernels differ in workgroup size)
         // level 2 (nodes + spheres) exists but is not selected: on final_scene it measured 10 % slower than level 1
         // (behind the stacks: the world's sequence, and the instrumented kernels' profile rows)
         const size_t budget = LDS_BUDGET_BYTES - 4096 - cs.oseq.size() * sizeof(OSeq);
+        const bool with_filter = flat_quads && total_filt + stack3 <= budget;
+        const size_t total = with_filter ? total_filt : total_plain;
         s->lds_level = total + stack3 <= budget ? 3 : (off_sph + stack1 <= budget ? 1 : 0);
         if (cs.ordered && n >= (wide ? (size_t)WIDE_MAX_LDS_RECORDS : (size_t)0x3fffu)) s->lds_level = 0; // 2-byte stack entries: a record index in 14 bits + two skip bits (wide: 12 + 4 mask bits)
         if (s->lds_level) {
@@ -681,6 +696,11 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
             memcpy(base, tables.data(), off_sph);
             if (s->lds_level >= 2 && !cs.spheres.empty()) memcpy(base + off_sph, cs.spheres.data(), cs.spheres.size() * sizeof(Sphere));
             if (s->lds_level == 3 && !cs.quads.empty()) memcpy(base + off_quads, cs.quads.data(), cs.quads.size() * sizeof(Quad));
+            if (s->lds_level == 3 && with_filter) {
+                const std::vector<QFiltPair> qf = qfilt_table(cs.quads);
+                memcpy(base + off_qfilt, qf.data(), qf.size() * sizeof(QFiltPair));
+                s->lds_off_qfilt = (uint32_t)off_qfilt;
+            }
             int urc = upload(s->lds_image, img);
             if (urc != RT_OK) { free_scene(s); return urc; }
             s->lds_off_spheres = (uint32_t)off_sph; s->lds_off_quads = (uint32_t)off_quads;

@@ -74,6 +74,7 @@ struct Tuning {
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     int wide = -1;         // own trees with four-child records (rt_layout.h ONode4): 1 always, 0 never, -1 for scenes of 64 primitives or more (RT_WIDE)
+    int quad_filter = 1;   // multi-quad leaves go through the conservative f32 filter before the exact test (RT_QUAD_FILTER; rt_scene_options.quad_filter)
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
     int slow_min = 4, slow_age = 32; // KParams::slow_min / slow_age (RT_SLOW_MIN, RT_SLOW_AGE; slow_min 1: nobody waits)
     int seq_lookahead = 1;  // scenes with media: a query looks ahead at the boxes of the sequence's later steps when it starts (RT_SEQ_LOOKAHEAD)
@@ -118,6 +119,7 @@ struct rt_scene {
     int blocks_per_cu[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}; // [LDS level][counted?]
     rtapi::DeviceArray<uint4> lds_image;               // the LDS-resident copy of nodes / spheres / quads (if they fit)
     uint32_t lds_off_node_b = 0, lds_off_spheres = 0, lds_off_quads = 0, lds_image_bytes = 0;
+    uint32_t lds_off_qfilt = 0;                 // the quads' f32 filter records in the LDS image (0: none)
     bool has_instances = false;
     bool parks_colours = false;                 // some attenuation is a texture's value: launches need the colour stack (KParams::att_stack)
     int lds_level = 0;                          // 0 nothing fits, 1 nodes, 2 nodes + spheres, 3 nodes + spheres + quads

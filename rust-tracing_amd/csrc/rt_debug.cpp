@@ -1,5 +1,6 @@
 // rt_debug.cpp — the test and tuning hooks of include/rt_amd_debug.h (not part of the drop-in boundary).
 #include "rt_api.hpp"
+#include "rt_qfilt.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -267,6 +268,48 @@ int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, doubl
         }
     } while (0);
     (void)hipFree(dr); (void)hipFree(db); (void)hipFree(de); (void)hipFree(df);
+    return rc;
+}
+
+int rt_debug_quad_filter_tests(int64_t n, const double *rays, const double *quads, double tmin, double tmax, uint8_t *out_exact_hit,
+                               uint8_t *out_keep, int device) {
+    if (n <= 0 || !rays || !quads || !out_exact_hit || !out_keep) return fail(RT_ERR_INVALID_ARGUMENT, "rt_debug_quad_filter_tests: bad argument");
+    if (rt_device_count() <= device || device < 0) return fail(RT_ERR_NO_DEVICE, "rt_debug_quad_filter_tests: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<Quad> hq((size_t)n);
+    std::vector<QFiltPair> hf((size_t)n);
+    for (int64_t i = 0; i < n; ++i) { // Quad::new (src/quad.rs:24-27)
+        const double *s = quads + i * 9;
+        Quad &q = hq[(size_t)i];
+        memset(&q, 0, sizeof q);
+        for (int k = 0; k < 3; ++k) { q.q[k] = s[k]; q.u[k] = s[3 + k]; q.v[k] = s[6 + k]; }
+        const double nn[3] = {q.u[1] * q.v[2] - q.u[2] * q.v[1], q.u[2] * q.v[0] - q.u[0] * q.v[2], q.u[0] * q.v[1] - q.u[1] * q.v[0]};
+        const double n2 = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+        const double rl = 1.0 / std::sqrt(n2), rn = 1.0 / n2;
+        for (int k = 0; k < 3; ++k) { q.normal[k] = nn[k] * rl; q.w[k] = nn[k] * rn; }
+        q.d = q.normal[0] * q.q[0] + q.normal[1] * q.q[1] + q.normal[2] * q.q[2];
+        memset(&hf[(size_t)i], 0, sizeof(QFiltPair));
+        qfilt_fill(q, hf[(size_t)i], 0);
+        qfilt_fill(q, hf[(size_t)i], 1);
+    }
+    double *dr = nullptr;
+    Quad *dq = nullptr;
+    QFiltPair *df = nullptr;
+    uint8_t *de = nullptr, *dk = nullptr;
+    int rc = RT_OK;
+    do {
+        if (hipMalloc((void **)&dr, (size_t)n * 6 * sizeof(double)) != hipSuccess || hipMalloc((void **)&dq, (size_t)n * sizeof(Quad)) != hipSuccess ||
+            hipMalloc((void **)&df, (size_t)n * sizeof(QFiltPair)) != hipSuccess || hipMalloc((void **)&de, (size_t)n) != hipSuccess ||
+            hipMalloc((void **)&dk, (size_t)n) != hipSuccess) { rc = fail(RT_ERR_OUT_OF_MEMORY, "rt_debug_quad_filter_tests: hipMalloc failed"); break; }
+        if (hipMemcpy(dr, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dq, hq.data(), (size_t)n * sizeof(Quad), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(df, hf.data(), (size_t)n * sizeof(QFiltPair), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(RT_ERR_HIP, "rt_debug_quad_filter_tests: upload failed"); break; }
+        launch_debug_quad(n, dr, dq, df, tmin, tmax, de, dk);
+        if (hipMemcpy(out_exact_hit, de, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out_keep, dk, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(RT_ERR_HIP, "rt_debug_quad_filter_tests: download failed"); break;
+        }
+    } while (0);
+    (void)hipFree(dr); (void)hipFree(dq); (void)hipFree(df); (void)hipFree(de); (void)hipFree(dk);
     return rc;
 }
 

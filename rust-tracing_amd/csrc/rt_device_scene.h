@@ -397,6 +397,71 @@ RT_DEV OPair opair_of_box(const float b[6], const RayPair32 &r) {
     p.c0 = p.c1 = 0;
     return p;
 }
+// ---- conservative f32 filter for the quads of a flat leaf (rt_layout.h QFiltPair; bounds derived in rt_qfilt.hpp) -------------
+// Quad::hit (src/quad.rs:96-133) is a plane distance (one f64 division) and two oblique coordinates (two cross products): ~85
+// instructions a quad, and a flat leaf (Cornell's walls, a box's faces) holds six of which a ray hits one.  The filter computes t,
+// alpha, beta for TWO quads at a time in packed f32 with an absolute error bound beside each, and drops a quad only when one of
+// them is outside its range by more than its bound; the exact test then runs over the survivors alone.  It can only err towards
+// "keep" (tests/test_gpu_parity.py: the exact test never accepts what the filter dropped).
+struct QRay32 {
+    float ox, oy, oz, dx, dy, dz; // the ray, rounded to nearest
+    float om, dm;                 // max |o_i|, max |d_i|
+};
+RT_DEV QRay32 make_qray32(V3 o, V3 d) {
+    QRay32 r;
+    r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r.om) : "v"(r.ox), "v"(r.oy), "v"(r.oz));
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r.dm) : "v"(r.dx), "v"(r.dy), "v"(r.dz));
+    return r;
+}
+RT_DEV f32x2 pk_splat(float x) { return f32x2{x, x}; }
+RT_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); } // (v_pk_fma_f32; a splat folds into op_sel)
+// bit 0 / bit 1: the first / second quad of the pair may be hit within (tmin32, tmax32) — an interval that CONTAINS the exact one
+RT_DEV uint32_t quad_pair_keep(const QFiltPair *rec, const QRay32 &r, float tmin32, float tmax32) {
+    const float4 *q4 = reinterpret_cast<const float4 *>(rec);
+    const float4 c0 = q4[0], c1 = q4[1], c6 = q4[6];
+    const f32x2 nx{c0.x, c0.y}, ny{c0.z, c0.w}, nz{c1.x, c1.y}, D{c1.z, c1.w}, n1c{c6.x, c6.y}, dc{c6.z, c6.w};
+    f32x2 dn = nx * pk_splat(r.dx);
+    dn = pk_fma(ny, pk_splat(r.dy), dn);
+    dn = pk_fma(nz, pk_splat(r.dz), dn);
+    f32x2 nm = pk_fma(-nx, pk_splat(r.ox), D);
+    nm = pk_fma(-ny, pk_splat(r.oy), nm);
+    nm = pk_fma(-nz, pk_splat(r.oz), nm);
+    const f32x2 ed2 = n1c * pk_splat(r.dm);
+    const f32x2 en2 = pk_fma(n1c, pk_splat(r.om), dc);
+    const f32x2 rc{__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+    const f32x2 t = nm * rc;
+    const f32x2 at = __builtin_elementwise_abs(t);
+    const f32x2 et = pk_fma(at, pk_splat(0x1p-21f), pk_fma(at, ed2, en2) * __builtin_elementwise_abs(rc));
+    // the hit point and how far off it may be
+    const f32x2 px = pk_fma(t, pk_splat(r.dx), pk_splat(r.ox)), py = pk_fma(t, pk_splat(r.dy), pk_splat(r.oy)), pz = pk_fma(t, pk_splat(r.dz), pk_splat(r.oz));
+    const f32x2 ep = pk_fma(et, pk_splat(r.dm), pk_fma(at, pk_splat(r.dm), pk_splat(r.om)) * pk_splat(0x1p-21f));
+    const float4 c2 = q4[2], c3 = q4[3], c4 = q4[4], c5 = q4[5], c7 = q4[7], c8 = q4[8];
+    const f32x2 ax{c2.x, c2.y}, ay{c2.z, c2.w}, az{c3.x, c3.y}, aq{c3.z, c3.w}, bx{c4.x, c4.y}, by{c4.z, c4.w}, bz{c5.x, c5.y}, bq{c5.z, c5.w};
+    const f32x2 a1{c7.x, c7.y}, ka{c7.z, c7.w}, b1{c8.x, c8.y}, kb{c8.z, c8.w};
+    f32x2 al = pk_fma(ax, px, -aq);
+    al = pk_fma(ay, py, al);
+    al = pk_fma(az, pz, al);
+    f32x2 be = pk_fma(bx, px, -bq);
+    be = pk_fma(by, py, be);
+    be = pk_fma(bz, pz, be);
+    // by how much each value is outside its range beyond its bound (a positive FINITE excess drops the quad; NaN and inf never do)
+    const f32x2 s_lo = (pk_splat(tmin32) - t) - et, s_hi = (t - pk_splat(tmax32)) - et;
+    const f32x2 s_a = __builtin_elementwise_abs(al) - pk_fma(a1, ep, ka), s_b = __builtin_elementwise_abs(be) - pk_fma(b1, ep, kb);
+    uint32_t keep = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float m3, m;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(s_lo[k]), "v"(s_hi[k]), "v"(s_a[k]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m3), "v"(s_b[k]));
+        const bool guard_ok = __builtin_fabsf(dn[k]) > ed2[k];                    // (false for a NaN: keep)
+        const bool excess = __builtin_amdgcn_classf(m, 0x180);                     // positive denormal | positive normal
+        keep |= (guard_ok && excess) ? 0u : (1u << k);
+    }
+    return keep;
+}
+
 // The exact f64 test the kernel used before (and the oracle's tight mode): kept as the yardstick for the test hook
 RT_DEV bool box_miss_f64(const double lo[3], const double hi[3], V3 o, V3 d, double tmin, double tmax) {
     const double od[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};

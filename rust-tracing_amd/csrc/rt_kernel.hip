@@ -59,6 +59,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     constexpr bool HAS_SPHERES = (FEAT & F_SPHERES) != 0, HAS_QUADS = (FEAT & F_QUADS) != 0, HAS_FRAMES = (FEAT & F_FRAMES) != 0,
                    HAS_MEDIA = (FEAT & F_MEDIA) != 0, HAS_TEXTURES = (FEAT & F_TEXTURES) != 0;
     constexpr bool HAS_OTHER = HAS_FRAMES || HAS_MEDIA;
+    // the quads of a multi-quad leaf go through the conservative f32 filter first (rt_device_scene.h quad_pair_keep): scenes that live
+    // in the LDS whole (their filter records with them)
+    constexpr bool QFILT = ORDERED && LDS == 3 && HAS_QUADS;
     // parked attenuations loaded per trip when a path ends: 4 where registers allow (the general kernels at 128 registers
     // already spill; their 256-thread form has 168)
     constexpr uint32_t CHAIN = (HAS_TEXTURES && LDS != 0) ? 1u : 4u;
@@ -673,27 +676,54 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         } else if (HAS_QUADS && run == ST_QUAD) {
             // ---------------- Quad::hit (src/quad.rs:96-127): all quads of the leaf (HittableList order) ----------------
             if (stage == ST_QUAD) {
-                for (uint32_t q = prim_cur; q < prim_end; ++q) {
+                auto quad_hit = [&](uint32_t q) {
                     if (COUNT) cn.quad_tests++;
                     const Quad *qd = &quad_tab[q];
                     const V3 normal = ld3(qd->normal);
                     const double denom = dot(normal, d);
-                    if (__builtin_fabs(denom) < 1e-8) continue;
+                    if (__builtin_fabs(denom) < 1e-8) return;
                     const double t = (qd->d - dot(normal, o)) / denom;
-                    if (!(cur_tmin <= t && t <= cur_tmax)) continue; // Interval::contains (src/interval.rs:40-42)
+                    if (!(cur_tmin <= t && t <= cur_tmax)) return; // Interval::contains (src/interval.rs:40-42)
                     if constexpr (ORDERED) // the ordered walk settles ties explicitly (see wins_tie)
-                        if (t == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) && !wins_tie(qd->seq, true)) continue;
+                        if (t == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) && !wins_tie(qd->seq, true)) return;
                     const V3 intersection = o + d * t;
                     const V3 php = intersection - ld3(qd->q);
                     const V3 qw = ld3(qd->w);
                     const double alpha = dot(qw, cross(php, ld3(qd->v)));
                     const double beta = dot(qw, cross(ld3(qd->u), php));
-                    if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) continue;
+                    if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) return;
                     cur_tmax = t;
                     tmax32 = ORDERED ? f32_above(t) : (float)t;
                     if (!HAS_MEDIA || (mode & 3u) == 0) { if (HAS_MEDIA) best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
                     else mode |= 0x100u;
+                };
+                bool filtered = false;
+                if constexpr (QFILT) {
+                    // A leaf of several quads (flat leaves: Cornell's walls, the faces of a box): the conservative f32 filter looks at
+                    // all of them, two at a time, against the interval as it is now, and the exact test runs for the lane's own
+                    // survivors only, in list order (the wave iterates as often as its worst lane has survivors: once or twice, not six
+                    // times).  A quad the filter drops is one the exact test would reject whatever the interval has shrunk to by then.
+                    if (P.lds_off_qfilt != 0xffffffffu) { // (wave-uniform)
+                        filtered = true;
+                        const uint32_t count = prim_end - prim_cur;
+                        uint32_t keep = 1u;
+                        if (count > 1u) {
+                            const QRay32 qr = make_qray32(o, d);
+                            const QFiltPair *rec = reinterpret_cast<const QFiltPair *>(lds_raw + P.lds_off_qfilt) + prim_cur;
+                            keep = 0u;
+#pragma unroll 1
+                            for (uint32_t k = 0; k < count; k += 2u) keep |= quad_pair_keep(rec + k, qr, tmin32, tmax32) << k;
+                            keep &= (1u << count) - 1u;
+                        }
+                        while (keep != 0u) {
+                            const uint32_t k = (uint32_t)__builtin_ctz(keep);
+                            keep &= keep - 1u;
+                            quad_hit(prim_cur + k);
+                        }
+                    }
                 }
+                if (!filtered)
+                    for (uint32_t q = prim_cur; q < prim_end; ++q) quad_hit(q);
                 prim_cur = prim_end;
                 if constexpr (ORDERED) o_next(false, 0u);
                 else stage = node >= n_nodes ? ST_SHADE : ST_BOX;
@@ -1206,6 +1236,31 @@ __global__ void debug_box_kernel(int64_t n, const double *__restrict__ rays, con
     f32_hit[idx] = (uint8_t)((single ? 1 : 0) | (m0 ? 0 : 2) | (m1 ? 0 : 4)); // bit 0: box_miss_f32, bits 1-2: box_pair_f32
 }
 
+// test hook: the quad stage's conservative f32 filter against the exact f64 Quad::hit on caller-supplied (ray, quad) pairs
+__global__ void debug_quad_kernel(int64_t n, const double *__restrict__ rays, const Quad *__restrict__ quads, const QFiltPair *__restrict__ filt,
+                                  double tmin, double tmax, uint8_t *__restrict__ exact_hit, uint8_t *__restrict__ keep) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const double *r = rays + idx * 6;
+    const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
+    const Quad *qd = &quads[idx];
+    bool hit = false; // src/quad.rs:96-127, as the quad stage runs it
+    const V3 normal = ld3(qd->normal);
+    const double denom = dot(normal, d);
+    if (!(__builtin_fabs(denom) < 1e-8)) {
+        const double t = (qd->d - dot(normal, o)) / denom;
+        if (tmin <= t && t <= tmax) {
+            const V3 php = (o + d * t) - ld3(qd->q);
+            const V3 qw = ld3(qd->w);
+            const double alpha = dot(qw, cross(php, ld3(qd->v)));
+            const double beta = dot(qw, cross(ld3(qd->u), php));
+            hit = !(alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0);
+        }
+    }
+    exact_hit[idx] = hit ? 1 : 0;
+    keep[idx] = (uint8_t)quad_pair_keep(&filt[idx], make_qray32(o, d), f32_below(tmin), f32_above(tmax)); // (the quad sits in both slots)
+}
+
 // test hook: evaluates one device-side scalar function over arrays (rt_debug_eval)
 __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restrict__ a, const double *__restrict__ b,
                                   double *__restrict__ out) {
@@ -1306,6 +1361,9 @@ void launch_resolve_rgb8(int64_t n_values, double inv_spp, const double *sum, ui
 }
 void launch_debug_box(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *exact_hit, uint8_t *f32_hit) {
     hipLaunchKernelGGL(debug_box_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, rays, boxes, tmin, tmax, exact_hit, f32_hit);
+}
+void launch_debug_quad(int64_t n, const double *rays, const Quad *quads, const QFiltPair *filt, double tmin, double tmax, uint8_t *exact_hit, uint8_t *keep) {
+    hipLaunchKernelGGL(debug_quad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, rays, quads, filt, tmin, tmax, exact_hit, keep);
 }
 void launch_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out) {
     hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, a, b, out);

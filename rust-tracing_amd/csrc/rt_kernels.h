@@ -66,6 +66,7 @@ struct KParams {
     const uint4 *lds_image;
     uint32_t lds_image_bytes;
     uint32_t lds_off_node_b, lds_off_spheres, lds_off_quads;
+    uint32_t lds_off_qfilt;         // the quads' f32 filter records (rt_layout.h QFiltPair), behind the quads; 0xffffffff: none, every quad gets the exact test
     double *world_slots;            // [6][n_threads] doubles: a lane's world-frame ray while it walks inside a frame
     uint32_t lds_world_off;         // ... or, where the LDS has room, [6][block threads] doubles there (0xffffffff: global memory)
     // ordered layout (rt_layout.h): records, the world frame's root, and where the per-lane stacks start in the LDS
@@ -147,6 +148,7 @@ void launch_tiles_to_frame_rgb8(int32_t w, int32_t h, int32_t tiles_x, int32_t s
                                 uint8_t *frame, hipStream_t stream);
 void launch_resolve_rgb8(int64_t n_values, double inv_spp, const double *sum, uint8_t *rgb, hipStream_t stream);
 void launch_debug_box(int64_t n, const double *rays, const double *boxes, double tmin, double tmax, uint8_t *exact_hit, uint8_t *f32_hit);
+void launch_debug_quad(int64_t n, const double *rays, const Quad *quads, const QFiltPair *filt, double tmin, double tmax, uint8_t *exact_hit, uint8_t *keep);
 void launch_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out);
 
 } // namespace rtk

@@ -120,6 +120,17 @@ struct alignas(16) Quad {
 };
 static_assert(sizeof(Quad) == 144, "Quad must be 144 bytes");
 
+// Conservative f32 filter records for the quads of a flat leaf (rt_device_scene.h quad_pair_keep): one record per quad index i, holding
+// the pair (i, i + 1) interleaved — (value of quad i, value of quad i + 1) — so that one packed f32 instruction serves both; the
+// quad stage reads the records of its leaf's first, third, fifth ... quad.  Built by rt_qfilt.hpp (host), LDS-resident scenes only.
+//   [0..2] normal  [3] d  [4..6] A = v x w  [7] A.q + 1/2  [8..10] B = w x u  [11] B.q + 1/2
+//   [12] 14 * 2^-24 * |normal|_1 (+inf: never filter this quad)  [13] 14 * 2^-24 * |d|  [14] |A|_1  [15] 1/2 + K_alpha  [16] |B|_1  [17] 1/2 + K_beta
+// so that alpha - 1/2 = A . p - [7] and beta - 1/2 = B . p - [11] at the hit point p (src/quad.rs:117-127: alpha = w . (php x v) = php . (v x w)).
+struct alignas(16) QFiltPair {
+    float v[18][2];
+};
+static_assert(sizeof(QFiltPair) == 144, "QFiltPair must be 144 bytes");
+
 // One frame change: optional Translate (applied to the ray first) then optional RotateY, i.e. the reference's
 // Translate::hit -> RotateY::hit nesting (src/hittable.rs:96-106,:159-188).  parent = enclosing instance or -1.
 struct alignas(64) Instance {

@@ -126,6 +126,53 @@ def test_f32_box_test_never_misses_what_the_exact_test_enters(rt, gpu):
     assert (~pair).sum() > 0.99 * (~exact).sum(), ((~pair).sum(), (~exact).sum())
 
 
+def test_f32_quad_filter_never_drops_what_the_exact_test_accepts(rt, gpu):
+    """A multi-quad leaf's quads go through a packed f32 filter (t, alpha, beta with error bounds) and only the survivors get the exact
+    f64 Quad::hit.  The filter may keep a quad the exact test rejects (a wasted test), never drop one it accepts: random and adversarial
+    cases — rays aimed at corners, edges and the interior, grazing the plane, origins on the plane, skewed and sliver parallelograms,
+    huge and tiny scales, far-away origins, zero and denormal direction components — over several intervals."""
+    rng = np.random.default_rng(4242)
+    n = 2_000_000
+    scale = 10.0 ** rng.uniform(-2, 3.5, (n, 1))
+    q0 = rng.uniform(-1, 1, (n, 3)) * scale
+    u = rng.uniform(-1, 1, (n, 3)) * scale * 10.0 ** rng.uniform(-2, 0, (n, 1))
+    v = rng.uniform(-1, 1, (n, 3)) * scale * 10.0 ** rng.uniform(-2, 0, (n, 1))
+    axis = rng.random(n) < 0.4                                               # axis-aligned rectangles (every wall of the Cornell box)
+    ax = rng.integers(0, 3, n)
+    for k in range(3):
+        m = axis & (ax == k)
+        u[m, k] = 0.0; u[m, (k + 1) % 3] = 0.0
+        v[m, k] = 0.0; v[m, (k + 2) % 3] = 0.0
+    sliver = rng.random(n) < 0.1
+    v[sliver] = u[sliver] * rng.uniform(0.5, 2.0, (int(sliver.sum()), 1)) + v[sliver] * 1e-3   # nearly parallel edges
+    ab = rng.choice([0.0, 1.0, 0.5, 0.25, -1e-9, 1.0 + 1e-9], (n, 2), p=[0.25, 0.25, 0.2, 0.2, 0.05, 0.05])
+    target = q0 + ab[:, :1] * u + ab[:, 1:] * v
+    o = q0 + rng.uniform(-1.5, 1.5, (n, 3)) * scale * rng.choice([1.0, 100.0], (n, 1), p=[0.9, 0.1])
+    on_plane = rng.random(n) < 0.05
+    o[on_plane] = (q0 + rng.uniform(-1, 2, (n, 1)) * u + rng.uniform(-1, 2, (n, 1)) * v)[on_plane]
+    d = (target - o) * 10.0 ** rng.uniform(-3, 3, (n, 1))
+    graze = rng.random(n) < 0.05
+    d[graze] = (u * rng.uniform(-1, 1, (n, 1)) + v * rng.uniform(-1, 1, (n, 1)) + (target - o) * 1e-7)[graze]
+    d[rng.random(n) < 0.05, rng.integers(0, 3)] = 0.0
+    d[rng.random(n) < 0.01] *= 1e-42                                          # denormal in f32
+    d = d * (1.0 + rng.integers(-4, 5, (n, 3)) * 2.0 ** -52)
+    rays = np.concatenate([o, d], axis=1)
+    quads = np.concatenate([q0, u, v], axis=1)
+    for tmin, tmax in ((0.001, np.inf), (0.001, 1.0), (-np.inf, np.inf), (0.999999, 1.000001), (1.0, 1.0)):
+        exact, keep = rt.debug_quad_filter_tests(rays, quads, tmin, tmax)
+        bad = exact & ~keep
+        assert not bad.any(), (tmin, tmax, int(bad.sum()), rays[bad][:3], quads[bad][:3])
+        if tmin == 0.001 and tmax == np.inf:
+            assert exact.sum() > 0.2 * n  # (the aimed rays do hit)
+    # ... and it is a filter: rays aimed well off the parallelogram are dropped almost as often as the exact test rejects them
+    ab = rng.uniform(-2.0, 3.0, (n, 2))
+    target = q0 + ab[:, :1] * u + ab[:, 1:] * v
+    rays = np.concatenate([o, target - o], axis=1)
+    exact, keep = rt.debug_quad_filter_tests(rays, quads, 0.001, np.inf)
+    assert not (exact & ~keep).any()
+    assert (~exact).sum() > 0.5 * n and (~keep).sum() > 0.98 * (~exact).sum(), ((~keep).sum(), (~exact).sum())
+
+
 # ---- whole-frame parity, every scene of the reference ---------------------------------------------------
 @pytest.mark.parametrize("name", list(scene_cases.CASES))
 def test_frame_is_bit_identical_to_oracle(rt, oracle, gpu, name):
