@@ -68,17 +68,46 @@ def algorithmic_work_per_sample(cnt):
 def relaunch_under_torchrun(n_ranks):
     """--gpus N > 1 from a bare shell: one child process runs torch.distributed.run with N ranks of this script.  Nothing in
     this process has touched a GPU (no HIP call, no torch.cuda call), and the launcher is a child, not an exec."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    # --standalone: torchrun's own c10d rendezvous picks a free port itself (binding port 0 here and handing the number on would
+    # leave a window in which another process can take it); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n_ranks}", str(Path(__file__).resolve()), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.run(cmd, env=env).returncode
+
+
+SETUP_TIMEOUT_S = 120  # every blocking step of the multi-rank set-up gives up after this long: an error line, never a hang
+
+
+def die(rank, what):
+    """One line on stderr that names the rank and the step, then a non-zero exit (os._exit: a rank stuck inside a collective or
+    an RCCL bootstrap has threads that would keep a normal exit waiting)."""
+    print(f"bench.py rank {rank}: {what}", file=sys.stderr, flush=True)
+    os._exit(3)
+
+
+def bounded(rank, what, fn, seconds=SETUP_TIMEOUT_S):
+    """fn() on a worker thread, at most `seconds`: its result, or its exception re-raised here; die() if it does not return."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:  # noqa: BLE001 (handed to the caller)
+            box["error"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        die(rank, f"{what} did not return within {seconds} s (a peer that never arrived, or a refused RCCL bootstrap)")
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
 
 
 def main():
@@ -118,16 +147,26 @@ def main():
     rehearsal = args.backend == "gloo"
     if rehearsal:
         local_rank = 0
-    if rt.amd_lib().rt_device_count() <= local_rank:
-        raise SystemExit("bench.py: no HIP device for this rank; the renderer has no CPU path")
+    n_devices = rt.amd_lib().rt_device_count()
+    if n_devices <= local_rank:
+        die(rank, f"no HIP device for local rank {local_rank} ({n_devices} visible); the renderer has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        from datetime import timedelta
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=SETUP_TIMEOUT_S))
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timedelta(seconds=SETUP_TIMEOUT_S))
+                # the first collective is where RCCL's communicator really comes up: do it here, bounded, not inside the timed region
+                probe = torch.ones(1, dtype=torch.int32, device=dev)
+                bounded(rank, "the first all-reduce over RCCL", lambda: (dist.all_reduce(probe), torch.cuda.synchronize()))
+                if int(probe.item()) != world:
+                    die(rank, f"the first all-reduce over RCCL returned {int(probe.item())}, not the world size {world}")
+        except Exception as e:  # noqa: BLE001
+            die(rank, f"torch.distributed set-up failed ({args.backend}, world {world}): {type(e).__name__}: {e}")
 
     wl = dict(WORKLOADS[args.workload])
     wl_name = wl.pop("name")
@@ -148,6 +187,9 @@ def main():
 
     stream = torch.cuda.current_stream()
     frame = torch.zeros(w * h * 3, dtype=torch.float64, device=dev)
+    # render = kernels + gather + D2H.  Rank 0 brings every step's frame to a pinned host buffer inside the timed
+    # region (the reference's render() ends with the Vec<Color> in host memory, src/renderer.rs:49-51).
+    host_frame_buf = torch.empty(w * h * 3, dtype=torch.float64, pin_memory=True) if rank == 0 else None
     if world > 1:
         stride = rtdist.shard_stride(w, h, world)
         tiles = torch.zeros(stride, dtype=torch.float64, device=dev)
@@ -171,8 +213,8 @@ def main():
             ids, why = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
         if ids[0] is not None:
-            try:
-                comm = rt.Comm.create(ids[0], rank, world, local_rank)
+            try:  # (ncclCommInitRank blocks until every rank has arrived: bounded)
+                comm = bounded(rank, "rt_comm_create (ncclCommInitRank through librt_amd)", lambda: rt.Comm.create(ids[0], rank, world, local_rank))
             except rt.RtError as e:
                 why = str(e)
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
@@ -212,6 +254,8 @@ def main():
                 rtdist.gather_tiles(tiles, gathered, rank, world)
             if rank == 0:
                 rt.tiles_to_frame_device(w, h, world, gathered.data_ptr(), frame.data_ptr(), stream.cuda_stream)
+        if rank == 0:
+            host_frame_buf.copy_(frame, non_blocking=True)  # (on `stream`, behind the kernels; the closing synchronize waits for it)
         return ev0, ev1
 
     def barrier():
@@ -251,8 +295,9 @@ def main():
         samples_per_launch = w * h * spp / world
         k_ms = sum(kernel_ms) / len(kernel_ms)
         tflops = flops_ps * samples_per_launch / (k_ms * 1e-3) / 1e12
-        host_frame = frame.cpu().numpy()
+        host_frame = host_frame_buf.numpy()  # what the last timed step downloaded
         assert np.isfinite(host_frame).all() and host_frame.max() > 0.0, "rendered frame is empty or not finite"
+        assert np.array_equal(host_frame, frame.cpu().numpy()), "the timed download differs from the device frame"
 
         total_samples = float(w) * h * spp * args.steps
         value = total_samples / elapsed / 1e6
@@ -260,17 +305,47 @@ def main():
         # tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction), committed per workload in
         # profiles/hbm_traffic.json together with the tag of the build they were measured on
         traffic, traffic_source, hbm_frac = None, "no PMC pass of this workload is committed under profiles/", None
+        traffic_parts, lane_util, valu_busy, pmc_source = None, None, None, None
         tp = ROOT / "profiles" / "hbm_traffic.json"
+        sys.path.insert(0, str(ROOT / "tools"))
+        try:
+            from source_hash import source_hash
+            sources_now = source_hash()
+        except Exception:
+            sources_now = None
+
+        def stale(entry_hash):  # committed counters are quoted only for the kernel sources this run was built from
+            return entry_hash is None or sources_now is None or entry_hash != sources_now
+
         if tp.exists() and world == 1 and args.spp == 0:
             try:
                 entry = json.loads(tp.read_text()).get(args.workload)
+                if entry and stale(entry.get("source_hash")):
+                    traffic_source = (f"profiles/hbm_traffic.json holds this workload's counters for sources {entry.get('source_hash')} "
+                                      f"({entry.get('tag')}); this run is built from {sources_now}: not quoted")
+                    entry = None
                 if entry:
-                    traffic = entry.get("bytes_per_launch")
+                    traffic = entry.get("bytes_per_launch")  # render kernel + per-pixel summation (what the timed kernels move)
+                    traffic_parts = {k: entry[k] for k in ("render_kernel_bytes", "sum_samples_kernel_bytes") if k in entry}
                     if traffic:  # measured bytes of one step / this run's kernel time of one step / 8 TB/s
                         hbm_frac = round(float(traffic) / (k_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, 5)
                     traffic_source = f"profiles/hbm_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build {entry.get('tag')}"
             except Exception:
                 pass
+        # the SQ counters that explain `frac` (lanes per VALU instruction, VALU issue): the newest committed PMC summary of this workload
+        if world == 1 and args.spp == 0:
+            pmcs = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{args.workload}_pmc.json"))
+            if pmcs:
+                try:
+                    sq = json.loads(pmcs[-1].read_text())
+                    if stale(sq.get("source_hash")):
+                        raise ValueError("counters of another build")
+                    lane_util = round(float(sq["valu_lane_utilisation"]), 4)
+                    if "valu_busy" in sq:
+                        valu_busy = round(float(sq["valu_busy"]), 4)
+                    pmc_source = f"profiles/{pmcs[-1].name}, rocprofv3 --pmc SQ passes of this command (one frame), build {sq.get('_tag', 'see file')}"
+                except Exception:
+                    pmc_source = f"profiles/{pmcs[-1].name} was measured on other kernel sources than this run's ({sources_now}): not quoted"
         result = {
             "metric": "Msamples/sec (pixels x spp / render seconds)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -280,10 +355,12 @@ def main():
                        "width": w, "height": h, "spp": spp, "max_depth": hs.camera.max_depth,
                        "parallelism": (f"tiles{world}" if world > 1 else "single") + (" [gloo rehearsal on one GPU]" if rehearsal else "")},
             "gather": gather_used,
+            "timed_region": "render kernels" + (" + gather + frame reassembly" if world > 1 else "") + f" + D2H of the frame to pinned host memory ({w * h * 24 / 1e6:.1f} MB per step)",
             "roofline": {
                 "bound": "valu_f64", "achieved": round(tflops, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic, "hbm_frac": hbm_frac,
-                "traffic_source": traffic_source,
+                "traffic_parts": traffic_parts, "traffic_source": traffic_source,
+                "valu_lane_utilisation": lane_util, "valu_busy": valu_busy, "pmc_source": pmc_source,
                 "kernel": "path_kernel (render megakernel) + sum_samples_kernel", "kernel_ms": round(k_ms, 3),
                 "launches_per_step": launches_per_step,
                 "sample_buffer_bytes": sample_buffer or "library default (2 GiB, two pipelined halves)",

@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 using namespace rtapi;
@@ -39,13 +40,19 @@ struct Rccl {
 const Rccl &rccl() {
     static Rccl r = [] {
         Rccl x;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (x.handle) break;
+        // RT_RCCL_LIB names the library to bind (a site's own RCCL build; the test suite's in-process stand-in): then that one or none
+        const char *chosen = getenv("RT_RCCL_LIB");
+        if (chosen && *chosen) {
+            x.handle = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                x.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (x.handle) break;
+            }
         }
         if (!x.handle) {
             const char *e = dlerror();
-            x.error = std::string("librccl.so could not be loaded: ") + (e ? e : "unknown reason");
+            x.error = std::string(chosen && *chosen ? "RT_RCCL_LIB could not be loaded: " : "librccl.so could not be loaded: ") + (e ? e : "unknown reason");
             return x;
         }
         auto sym = [&](const char *name) -> void * {

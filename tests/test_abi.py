@@ -169,3 +169,17 @@ def test_the_rust_binding_in_integration_md_covers_rt_amd_h(rt):
         assert m, f"INTEGRATION.md declares no struct {cname}"
         fields = re.findall(r"pub (\w+)\s*:", m.group(1))
         assert fields == [f for f, _ in cls._fields_], (cname, fields)
+
+
+def test_the_rccl_stand_in_of_the_test_suite_exports_what_the_gather_binds():
+    """tests/rccl_stub (test infrastructure: RT_RCCL_LIB in tests/test_gpu_gather_stub.py) must define every RCCL entry point that
+    rust-tracing_amd/csrc/rt_gather.cpp looks up — and the product must not know the stub exists."""
+    stub = ROOT / "tests" / "rccl_stub" / "librccl_stub.so"
+    assert stub.exists(), "run __graft_entry__.build()"
+    wanted = set(re.findall(r'sym\("(nccl\w+)"\)', (ROOT / "rust-tracing_amd" / "csrc" / "rt_gather.cpp").read_text()))
+    assert len(wanted) >= 11
+    exported = {line.split()[-1] for line in subprocess.run(["nm", "-D", "--defined-only", str(stub)], check=True, capture_output=True, text=True).stdout.splitlines()}
+    assert wanted <= exported, wanted - exported
+    for src in (ROOT / "rust-tracing_amd").rglob("*"):
+        if src.is_file() and src.suffix in (".cpp", ".hpp", ".h", ".hip", ".py"):
+            assert "rccl_stub" not in src.read_text(errors="ignore"), src

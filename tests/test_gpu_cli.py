@@ -48,3 +48,24 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell(rt, gpu):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
     assert "gloo" in line["gather"] and line["config"]["workload"].startswith("random-spheres 400x225")
+
+
+def test_bench_with_more_ranks_than_gpus_fails_loudly_and_soon(rt, gpu):
+    """`python bench.py --gpus 2 --backend nccl` on a box with ONE GPU: the rank without a device says so on stderr and the whole
+    launch ends with a non-zero exit code well inside three minutes — it must not sit in a rendezvous or an RCCL bootstrap.  (What the
+    first contact with a real multi-GPU node would look like if a device were missing or refused.)"""
+    import os
+    import sys
+    import time
+    if gpu > 1:
+        pytest.skip("this box has a second GPU: the launch would be a real two-rank run")
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "nccl", "--workload", "c1", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+    took = time.time() - t0
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert took < 180, f"took {took:.0f} s"
+    assert "bench.py rank 1: no HIP device for local rank 1" in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "a result line was printed by a launch that failed"

@@ -17,6 +17,15 @@ SRC = ROOT / "gpurun_out" / "prof"
 DST = ROOT / "profiles"
 tag = sys.argv[1]
 KERNEL = "path_kernel<false"  # the un-instrumented render kernel (bench.py's counting passes use path_kernel<true)
+SUM_KERNEL = "sum_samples_kernel"  # the per-pixel summation behind it: reads the whole sample buffer back
+sys.path.insert(0, str(ROOT / "tools"))
+from source_hash import source_hash  # noqa: E402
+
+# a profile is filed only for the sources it was measured on: the hash the box recorded must be the working tree's
+measured = (SRC / "source_hash.txt").read_text().strip() if (SRC / "source_hash.txt").exists() else None
+if measured != source_hash() and "--force" not in sys.argv:
+    sys.exit(f"collect_profiles.py: gpurun_out/prof/ was measured on sources {measured}, the working tree is {source_hash()}: "
+             "re-run tools/profile_round.sh on this build (or pass --force and say so in DESIGN.md)")
 
 
 def one(pattern):
@@ -25,13 +34,13 @@ def one(pattern):
     return Path(hits[-1])  # (gpurun merges into gpurun_out/ without clearing it: take the latest run's file)
 
 
-def counters(run):
-    """Sum of each counter over the render kernel's dispatches (one frame = one bench step: --steps 1 --warmup 0; a frame that
+def counters(run, kernel=KERNEL):
+    """Sum of each counter over the dispatches of `kernel` (one frame = one bench step: --steps 1 --warmup 0; a frame that
     needs several launches has several dispatches)."""
     out, dispatches = {}, set()
     with open(one(f"{run}/*/*_counter_collection.csv")) as f:
         for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"]:
+            if kernel in row["Kernel_Name"]:
                 out[row["Counter_Name"]] = out.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                 dispatches.add(row["Dispatch_Id"])
                 out["_kernel"] = row["Kernel_Name"]
@@ -48,12 +57,16 @@ for w in ("c1", "c2", "c3", "c4", "c5"):
             continue
         shutil.copy(SRC / "bench_c5.json", DST / f"{tag}_bench_c5_1gpu.json")
         fetch, write = counters("fetch_c5"), counters("write_c5")
-        traffic = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+        sfetch, swrite = counters("fetch_c5", SUM_KERNEL), counters("write_c5", SUM_KERNEL)
+        render_bytes = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+        sum_bytes = sfetch.get("FETCH_SIZE", 0.0) * 1024 * 2 + swrite.get("WRITE_SIZE", 0.0) * 1024
+        traffic = render_bytes + sum_bytes
         bench = json.load(open(SRC / "bench_c5.json"))
-        hbm[w] = {"bytes_per_launch": traffic, "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
+        hbm[w] = {"bytes_per_launch": traffic, "render_kernel_bytes": render_bytes, "sum_samples_kernel_bytes": sum_bytes,
+                  "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
                   "dispatches_per_frame": fetch["_dispatches_per_frame"],
                   "achieved_GBps": round(traffic / (bench["roofline"]["kernel_ms"] * 1e-3) / 1e9, 1),
-                  "formula": "as c1..c4", "kernel": fetch["_kernel"], "tag": f"{tag} ({commit})",
+                  "formula": "as c1..c4", "kernel": fetch["_kernel"], "tag": f"{tag} ({commit}, sources {measured})", "source_hash": measured,
                   "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline"}
         print("c5", bench["value"], "Msamples/s; HBM", round(traffic / 1e9, 2), "GB/frame")
         continue
@@ -65,21 +78,31 @@ for w in ("c1", "c2", "c3", "c4", "c5"):
     fetch, write = counters(f"fetch_{w}"), counters(f"write_{w}")
     # MI355X_MICROARCH.md, HBM / rocprofv3: FETCH_SIZE and WRITE_SIZE are in KiB, each in its own pass; gfx950 reports half
     # of the bytes fetched (x2 correction)
-    traffic = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+    sfetch, swrite = counters(f"fetch_{w}", SUM_KERNEL), counters(f"write_{w}", SUM_KERNEL)
+    render_bytes = fetch["FETCH_SIZE"] * 1024 * 2 + write["WRITE_SIZE"] * 1024
+    sum_bytes = sfetch.get("FETCH_SIZE", 0.0) * 1024 * 2 + swrite.get("WRITE_SIZE", 0.0) * 1024
+    traffic = render_bytes + sum_bytes  # what the timed step moves: the render kernel(s) and the per-pixel summation of their samples
     bench = json.load(open(SRC / f"bench_{w}.json"))
-    hbm[w] = {"bytes_per_launch": traffic, "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
+    hbm[w] = {"bytes_per_launch": traffic, "render_kernel_bytes": render_bytes, "sum_samples_kernel_bytes": sum_bytes,
+              "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"],
+              "sum_samples_FETCH_SIZE_KB": sfetch.get("FETCH_SIZE", 0.0), "sum_samples_WRITE_SIZE_KB": swrite.get("WRITE_SIZE", 0.0),
               "dispatches_per_frame": fetch["_dispatches_per_frame"],
               "achieved_GBps": round(traffic / (bench["roofline"]["kernel_ms"] * 1e-3) / 1e9, 1),
-              "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, summed over the frame's render-kernel dispatches (separate --pmc passes; "
+              "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, summed over the frame's render-kernel AND sum_samples_kernel dispatches (separate --pmc passes; "
                          "gfx950 FETCH_SIZE x2 correction; access widths here are 8 B per lane, outside the calibrated 16 B streaming case)",
               "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --workload {w} --steps 1 --warmup 0 --no-cpu-baseline",
-              "kernel": fetch["_kernel"], "tag": f"{tag} ({commit})"}
+              "kernel": fetch["_kernel"], "tag": f"{tag} ({commit}, sources {measured})", "source_hash": measured}
     if w == "c1":
         continue
     sq = {}
     for run in (f"sq1_{w}", f"sq2_{w}"):
         sq.update(counters(run))
     sq["valu_lane_utilisation"] = sq["SQ_THREAD_CYCLES_VALU"] / (sq["SQ_ACTIVE_INST_VALU"] * 64.0)
+    # share of the cycles in which a SIMD's VALU is issuing: ACTIVE_INST_VALU is counted per wave, a SIMD holds waves_per_simd of them
+    waves_per_simd = {"c2": 4, "c3": 4, "c4": 3}[w]
+    sq["valu_busy"] = min(1.0, sq["SQ_ACTIVE_INST_VALU"] * waves_per_simd / sq["SQ_WAVE_CYCLES"])
+    sq["_tag"] = f"{tag} ({commit}, sources {measured})"
+    sq["source_hash"] = measured
     sq["wait_inst_any_share_of_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
     sq["lds_bank_conflict_share_of_lds_active"] = sq["SQ_LDS_BANK_CONFLICT"] / max(1.0, sq["SQ_LDS_IDX_ACTIVE"])
     sq["hbm_bytes_per_frame"] = traffic

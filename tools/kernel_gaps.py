@@ -7,10 +7,16 @@ what shows that a chunked frame's render kernels run back to back across the two
 hides behind the next render kernel."""
 import csv, glob, sys
 
-f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))[-1]
+traces = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))
+if not traces:
+    sys.exit(f"kernel_gaps.py: no *_kernel_trace.csv under {sys.argv[1]}")
+f = traces[-1]
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 render = [i for i, r in enumerate(rows) if 'path_kernel<false' in r['Kernel_Name']]
+if not render:
+    sys.exit(f"kernel_gaps.py: no dispatch of the render kernel ('path_kernel<false') in {f}: "
+             f"kernel names seen: {sorted({r['Kernel_Name'][:60] for r in rows})[:8]}")
 # the last frame: walk back from the last render dispatch while the gaps between render dispatches stay under 5 ms
 last = render[-1]
 first = last

@@ -10,6 +10,7 @@ OUT="$ROOT/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT" || exit 1
 export TMPDIR=/tmp
+python3 tools/source_hash.py > "$OUT/source_hash.txt" || exit 1   # which sources these profiles are of (no .git on the box)
 for w in c2 c1 c3 c4; do
   timeout -k 10 600 python3 bench.py --workload $w > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
   echo "bench $w done"
@@ -29,7 +30,7 @@ for w in c2 c3 c4 c1; do
   echo "profiles $w done"
 done
 # C4's dispatch timeline (the last frame of the kernel trace above): render kernels back to back, sum_samples hidden
-python3 tools/kernel_gaps.py "$OUT/kt_c4" > "$OUT/timeline_c4.txt" 2>&1 || true
+python3 tools/kernel_gaps.py "$OUT/kt_c4" > "$OUT/timeline_c4.txt" 2> "$OUT/timeline_c4.err" || rm -f "$OUT/timeline_c4.txt"
 # C5 (final_scene 1600x1600, 10000 spp, depth 50) on this one GPU: the bench line and the HBM traffic of one frame (26 s each)
 timeout -k 10 400 python3 bench.py --workload c5 --steps 1 --warmup 0 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || exit 1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c5" -- python3 bench.py --workload c5 --no-cpu-baseline --steps 1 --warmup 0 > "$OUT/fetch_c5.log" 2>&1 || exit 1

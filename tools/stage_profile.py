@@ -28,5 +28,5 @@ for k, v in prof.items():
     if "." in k:
         print(f"  {k:15s} cycles {100 * v['cycles'] / total:5.1f} %")
         continue
-    print(f"{k:7s} rounds/sample {v['rounds'] * 64 / n:9.2f}  mean active lanes {v['mean_active_lanes']:5.1f}  cycles {100 * v['cycles'] / total:5.1f} %"
+    print(f"{k:7s} rounds per 64 samples {v['rounds'] * 64 / n:9.2f}  mean active lanes {v['mean_active_lanes']:5.1f}  cycles {100 * v['cycles'] / total:5.1f} %"
           f"  cycles/round {v['cycles'] / max(1, v['rounds']):8.1f}")
