@@ -34,8 +34,10 @@ int rt_debug_box_tests(int64_t n, const double *rays, const double *boxes, doubl
 /* Test hook: the quad stage's conservative f32 filter (rt_device_scene.h quad_pair_keep) and the exact f64 Quad::hit
  * (src/quad.rs:96-127) on n (ray, quad) pairs — rays[i] = (origin xyz, direction xyz), quads[i] = (Q xyz, u xyz, v xyz), the
  * derived fields as Quad::new computes them (src/quad.rs:24-27), interval [tmin, tmax].  out_exact_hit[i] = 1: the exact test
- * accepts; out_keep[i] bit 0 / bit 1: the filter keeps the quad in the first / second slot of its pair record.  The filter must
- * keep whatever the exact test accepts (tests/test_gpu_parity.py). */
+ * accepts; out_keep[i] bit 0 / bit 1: the filter keeps the quad in the first / second slot of its pair record; bit 2 / bit 3: it
+ * claims alpha and beta certainly inside [0, 1] (the exact test then skips them); bit 4: the exact alpha and beta ARE inside (1 also
+ * where the exact test ends before it gets to them).  The filter must keep whatever the exact test accepts, and may claim "inside"
+ * only where bit 4 is set (tests/test_gpu_parity.py). */
 int rt_debug_quad_filter_tests(int64_t n, const double *rays, const double *quads, double tmin, double tmax, uint8_t *out_exact_hit,
                                uint8_t *out_keep, int device);
 

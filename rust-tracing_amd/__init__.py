@@ -273,7 +273,8 @@ def debug_box_tests(rays, boxes, tmin, tmax, device=0):
 
 def debug_quad_filter_tests(rays, quads, tmin, tmax, device=0):
     """rt_debug_quad_filter_tests: per (ray, quad = Q, u, v) pair: does the exact f64 Quad::hit accept within [tmin, tmax]? does the
-    quad stage's conservative f32 filter keep the quad (both slots of the pair record must agree)?"""
+    quad stage's conservative f32 filter keep the quad (both slots of the pair record must agree)?  does it claim alpha and beta are
+    certainly inside [0, 1] — and are they, where the exact test evaluates them?"""
     import numpy as np
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     quads = np.ascontiguousarray(quads, dtype=np.float64).reshape(-1, 9)
@@ -283,8 +284,10 @@ def debug_quad_filter_tests(rays, quads, tmin, tmax, device=0):
     _check(amd_lib().rt_debug_quad_filter_tests(n, rays.ctypes.data_as(C.POINTER(C.c_double)), quads.ctypes.data_as(C.POINTER(C.c_double)),
                                                 tmin, tmax, exact.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                 keep.ctypes.data_as(C.POINTER(C.c_uint8)), device), "rt_debug_quad_filter_tests")
-    assert ((keep & 1) == ((keep >> 1) & 1)).all(), "the two slots of the pair record disagree on the same quad"
-    return exact.astype(bool), (keep & 1).astype(bool)
+    assert ((keep & 1) == ((keep >> 1) & 1)).all() and ((keep >> 2 & 1) == (keep >> 3 & 1)).all(), "the two slots of the pair record disagree on the same quad"
+    # exact verdict | the filter keeps the quad | the filter says alpha, beta are certainly inside | the exact alpha, beta are inside
+    # (True where the exact test did not get that far)
+    return exact.astype(bool), (keep & 1).astype(bool), (keep >> 2 & 1).astype(bool), (keep >> 4 & 1).astype(bool)
 
 
 def debug_compiled_nodes(host_scene, refit=True):

@@ -133,7 +133,7 @@ namespace {
 void free_scene(rt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    for (auto &kv : s->workspaces) free_workspace(kv.second);
+    for (auto &kv : s->workspaces) free_workspace(kv.second->w);
     (void)hipFree(s->nodes.ptr); (void)hipFree(s->spheres.ptr); (void)hipFree(s->quads.ptr); (void)hipFree(s->insts.ptr);
     (void)hipFree(s->media.ptr); (void)hipFree(s->mats.ptr); (void)hipFree(s->texs.ptr); (void)hipFree(s->perlins.ptr);
     (void)hipFree(s->images.ptr); (void)hipFree(s->texels.ptr); (void)hipFree(s->lut.ptr); (void)hipFree(s->lds_image.ptr); (void)hipFree(s->oimage.ptr); (void)hipFree(s->oseq.ptr); (void)hipFree(s->aux_image.ptr);
@@ -223,34 +223,54 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     if (grid < 1) grid = 1;
     const uint32_t n_threads = (uint32_t)(grid * threads);
 
-    // The scratch of this (scene, stream).  The entry is taken — and marked in use — under the scene's lock; the launches are
-    // enqueued outside it on a copy of the handles.  Only entries nobody holds are ever evicted, after waiting for the event their
-    // last render recorded (a library-owned handle: the caller's stream may be gone by then).
+    // The scratch of this (scene, stream).  Under the scene's lock: the table look-up, the in-use mark, and — a new stream and a full
+    // table — taking the idle slots OUT of the table.  Everything that can wait (an evicted slot's last render, a drain before a buffer
+    // grows, hipFree / hipMalloc) and the enqueues happen outside it, under the slot's own mutex: renders on other streams go on.
+    // Only slots nobody holds are ever evicted, after waiting for the event their last render recorded (a library-owned handle:
+    // the caller's stream may be gone by then).
     Workspace ws;
-    struct Release {
-        rt_scene *scene; hipStream_t stream; bool armed = false;
-        ~Release() {
-            if (!armed) return;
-            std::lock_guard<std::mutex> lock(scene->mu);
-            auto it = scene->workspaces.find(stream);
-            if (it != scene->workspaces.end() && it->second.in_use > 0) it->second.in_use--;
-        }
-    } release{scene, stream};
-    const bool colours = scene->parks_colours;
+    WorkspaceSlot *slot = nullptr;
+    std::vector<std::unique_ptr<WorkspaceSlot>> evicted;
     {
         std::lock_guard<std::mutex> lock(scene->mu);
         if (scene->workspaces.find(stream) == scene->workspaces.end() && scene->workspaces.size() >= MAX_WORKSPACES) {
-            // a new stream and the table is full: the idle entries go, once their last render has drained; entries in use stay
-            // (the table then grows past its nominal size rather than pull scratch from under a render that is being enqueued)
+            // (slots in use stay: the table then grows past its nominal size rather than pull scratch from under a render)
             for (auto it = scene->workspaces.begin(); it != scene->workspaces.end();) {
-                if (it->second.in_use != 0) { ++it; continue; }
-                if (it->second.ev_done) (void)hipEventSynchronize(it->second.ev_done);
-                free_workspace(it->second);
+                if (it->second->in_use != 0) { ++it; continue; }
+                evicted.push_back(std::move(it->second));
                 it = scene->workspaces.erase(it);
             }
-            (void)hipGetLastError();
         }
-        Workspace &w = scene->workspaces[stream];
+        std::unique_ptr<WorkspaceSlot> &entry = scene->workspaces[stream];
+        if (!entry) entry.reset(new WorkspaceSlot());
+        slot = entry.get();
+        slot->in_use++;
+    }
+    struct Release { // (declared before the slot's lock: runs after it is dropped)
+        rt_scene *scene; WorkspaceSlot *slot; hipStream_t stream;
+        bool enqueued = false, completed = false;
+        ~Release() {
+            // a render that failed after some launches were enqueued: what is in flight is waited for and the slot's event recorded all the
+            // same, so that a later eviction never frees scratch a kernel still uses
+            if (enqueued && !completed) {
+                for (int h = 0; h < 2; ++h) if (slot->w.aux[h]) (void)hipStreamSynchronize(slot->w.aux[h]);
+                if (slot->w.ev_done) (void)hipEventRecord(slot->w.ev_done, stream);
+                (void)hipGetLastError();
+            }
+            std::lock_guard<std::mutex> lock(scene->mu);
+            if (slot->in_use > 0) slot->in_use--;
+        }
+    } release{scene, slot, stream};
+    for (auto &old : evicted) {
+        if (old->w.ev_done) (void)hipEventSynchronize(old->w.ev_done);
+        free_workspace(old->w);
+    }
+    if (!evicted.empty()) (void)hipGetLastError();
+    evicted.clear();
+    const bool colours = scene->parks_colours;
+    std::unique_lock<std::mutex> slot_lock(slot->mu); // held to the end of the enqueues
+    {
+        Workspace &w = slot->w;
         const size_t need_att = colours ? ((size_t)p.max_depth + 1u) * n_threads * 3u * sizeof(double) : sizeof(double); // + a light's emitted colour
         if (need_att / sizeof(double) >= ((size_t)1 << 32)) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth too large for the attenuation stack's 32-bit indices");
         const size_t need_ids = ((size_t)p.max_depth + 1u) * n_threads * sizeof(uint32_t);
@@ -323,10 +343,9 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
             if (!x.job_counter) HIP_TRY(hipMalloc((void **)&x.job_counter, sizeof(uint32_t)));
         }
         if (!w.counters) HIP_TRY(hipMalloc((void **)&w.counters, COUNTER_WORDS * sizeof(unsigned long long)));
-        w.in_use++;
-        release.armed = true;
         ws = w;
     }
+    release.enqueued = true; // (from here on something may be in flight on `stream` or the internal streams)
     if (counted) HIP_TRY(hipMemsetAsync(ws.counters, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
 
     KParams K{};
@@ -419,6 +438,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(stream, ws.ev_sum[(k - 1) & 1], 0)); // (the last sum waited for all before it)
     HIP_TRY(hipEventRecord(ws.ev_done, stream));
+    release.completed = true;
     g_last_launch[0] = 0u; g_last_launch[1] = (uint32_t)lds; g_last_launch[2] = (uint32_t)threads; g_last_launch[3] = (uint32_t)grid;
 
     if (counted) {

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,11 +48,18 @@ struct Workspace {
     hipEvent_t ev_start = nullptr, ev_sum[2] = {nullptr, nullptr};
     hipEvent_t ev_done = nullptr;                 // recorded on the caller's stream behind every render's last enqueue: what an
                                                   // eviction waits for (the caller's stream handle itself is never touched again)
-    int in_use = 0;                               // renders that hold a copy of this entry and have not finished enqueueing
     size_t sample_budget = 0;                     // > 0: the sample buffer size an out-of-memory back-off arrived at
     unsigned long long *counters = nullptr;
 };
 void free_workspace(Workspace &w);
+// One per (scene, stream).  rt_scene::mu guards only the table and `in_use`; everything slow — draining the stream before a buffer
+// grows, hipFree / hipMalloc, creating the internal streams, the enqueues themselves — happens under the slot's own mutex, so renders
+// of one scene on DIFFERENT streams never wait for each other (renders on one stream are ordered anyway).
+struct WorkspaceSlot {
+    std::mutex mu;
+    Workspace w;
+    int in_use = 0; // renders that hold this slot (from the table look-up to the end of their enqueues): such a slot is never evicted
+};
 
 // Scheduler knobs (64ths of the live lanes a deferred stage must have queued / the box loop needs to keep running).
 // The best values depend on the stage mix, so there is one preset per kernel instantiation, each picked with
@@ -149,7 +157,7 @@ struct rt_scene {
     uint32_t o_start_stage = 0, o_start_prim = 0, o_start_end = 0, o_start_rest = 0, o_start_slot = 0; // KParams::o_start_*
     rt_scene_stats stats{};
     std::mutex mu;
-    std::map<hipStream_t, rtapi::Workspace> workspaces; // one per stream: launches on a stream are ordered
+    std::map<hipStream_t, std::unique_ptr<rtapi::WorkspaceSlot>> workspaces; // one per stream: launches on a stream are ordered
     rt_scene_options options;                    // the caller's per-scene options (rt_scene_create_ex); unset fields: process defaults
     std::mutex host_render_mu;                   // rt_render (host-buffer form) calls on one scene run one at a time
 };

@@ -289,8 +289,10 @@ int rt_debug_quad_filter_tests(int64_t n, const double *rays, const double *quad
         for (int k = 0; k < 3; ++k) { q.normal[k] = nn[k] * rl; q.w[k] = nn[k] * rn; }
         q.d = q.normal[0] * q.q[0] + q.normal[1] * q.q[1] + q.normal[2] * q.q[2];
         memset(&hf[(size_t)i], 0, sizeof(QFiltPair));
-        qfilt_fill(q, hf[(size_t)i], 0);
-        qfilt_fill(q, hf[(size_t)i], 1);
+    }
+    for (int64_t i = 0; i < n; ++i) { // (the quad sits in both slots of its record: the pair's bounds are its own)
+        qfilt_fill(hq[(size_t)i], hf[(size_t)i], 0);
+        qfilt_fill(hq[(size_t)i], hf[(size_t)i], 1);
     }
     double *dr = nullptr;
     Quad *dq = nullptr;

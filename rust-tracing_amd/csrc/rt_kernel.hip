@@ -676,7 +676,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
         } else if (HAS_QUADS && run == ST_QUAD) {
             // ---------------- Quad::hit (src/quad.rs:96-127): all quads of the leaf (HittableList order) ----------------
             if (stage == ST_QUAD) {
-                auto quad_hit = [&](uint32_t q) {
+                auto quad_hit = [&](uint32_t q, bool inside_known) { // inside_known: the filter has shown alpha, beta in [0, 1] for this t
                     if (COUNT) cn.quad_tests++;
                     const Quad *qd = &quad_tab[q];
                     const V3 normal = ld3(qd->normal);
@@ -686,12 +686,14 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (!(cur_tmin <= t && t <= cur_tmax)) return; // Interval::contains (src/interval.rs:40-42)
                     if constexpr (ORDERED) // the ordered walk settles ties explicitly (see wins_tie)
                         if (t == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) && !wins_tie(qd->seq, true)) return;
-                    const V3 intersection = o + d * t;
-                    const V3 php = intersection - ld3(qd->q);
-                    const V3 qw = ld3(qd->w);
-                    const double alpha = dot(qw, cross(php, ld3(qd->v)));
-                    const double beta = dot(qw, cross(ld3(qd->u), php));
-                    if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) return;
+                    if (!inside_known) { // (behind a branch the wave skips when every lane's survivor is a certain one — nearly always)
+                        const V3 intersection = o + d * t;
+                        const V3 php = intersection - ld3(qd->q);
+                        const V3 qw = ld3(qd->w);
+                        const double alpha = dot(qw, cross(php, ld3(qd->v)));
+                        const double beta = dot(qw, cross(ld3(qd->u), php));
+                        if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) return;
+                    }
                     cur_tmax = t;
                     tmax32 = ORDERED ? f32_above(t) : (float)t;
                     if (!HAS_MEDIA || (mode & 3u) == 0) { if (HAS_MEDIA) best_t = t; best_prim = PRIM_QUAD | q; best_inst = cur_inst; }
@@ -706,24 +708,25 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (P.lds_off_qfilt != 0xffffffffu) { // (wave-uniform)
                         filtered = true;
                         const uint32_t count = prim_end - prim_cur;
-                        uint32_t keep = 1u;
+                        uint32_t keep = 1u; // bits 0-7: survivors; bits 8-15: of them, those whose alpha and beta are known to be inside
                         if (count > 1u) {
                             const QRay32 qr = make_qray32(o, d);
                             const QFiltPair *rec = reinterpret_cast<const QFiltPair *>(lds_raw + P.lds_off_qfilt) + prim_cur;
                             keep = 0u;
 #pragma unroll 1
                             for (uint32_t k = 0; k < count; k += 2u) keep |= quad_pair_keep(rec + k, qr, tmin32, tmax32) << k;
-                            keep &= (1u << count) - 1u;
+                            keep &= ((1u << count) - 1u) * 0x101u;
                         }
-                        while (keep != 0u) {
+                        while ((keep & 0xffu) != 0u) {
                             const uint32_t k = (uint32_t)__builtin_ctz(keep);
+                            const bool inside_known = (keep >> (8u + k) & 1u) != 0u;
                             keep &= keep - 1u;
-                            quad_hit(prim_cur + k);
+                            quad_hit(prim_cur + k, inside_known);
                         }
                     }
                 }
                 if (!filtered)
-                    for (uint32_t q = prim_cur; q < prim_end; ++q) quad_hit(q);
+                    for (uint32_t q = prim_cur; q < prim_end; ++q) quad_hit(q, false);
                 prim_cur = prim_end;
                 if constexpr (ORDERED) o_next(false, 0u);
                 else stage = node >= n_nodes ? ST_SHADE : ST_BOX;
@@ -1244,7 +1247,7 @@ __global__ void debug_quad_kernel(int64_t n, const double *__restrict__ rays, co
     const double *r = rays + idx * 6;
     const V3 o = v3(r[0], r[1], r[2]), d = v3(r[3], r[4], r[5]);
     const Quad *qd = &quads[idx];
-    bool hit = false; // src/quad.rs:96-127, as the quad stage runs it
+    bool hit = false, inside = true; // src/quad.rs:96-127, as the quad stage runs it; inside: what the exact test finds for alpha, beta
     const V3 normal = ld3(qd->normal);
     const double denom = dot(normal, d);
     if (!(__builtin_fabs(denom) < 1e-8)) {
@@ -1254,11 +1257,13 @@ __global__ void debug_quad_kernel(int64_t n, const double *__restrict__ rays, co
             const V3 qw = ld3(qd->w);
             const double alpha = dot(qw, cross(php, ld3(qd->v)));
             const double beta = dot(qw, cross(ld3(qd->u), php));
-            hit = !(alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0);
+            inside = !(alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0);
+            hit = inside;
         }
     }
     exact_hit[idx] = hit ? 1 : 0;
-    keep[idx] = (uint8_t)quad_pair_keep(&filt[idx], make_qray32(o, d), f32_below(tmin), f32_above(tmax)); // (the quad sits in both slots)
+    const uint32_t bits = quad_pair_keep(&filt[idx], make_qray32(o, d), f32_below(tmin), f32_above(tmax));
+    keep[idx] = (uint8_t)((bits & 3u) | ((bits >> 8 & 3u) << 2) | (inside ? 16u : 0u)); // bits 0-1 keep, 2-3 certainly inside, 4: the exact alpha, beta ARE inside // (the quad sits in both slots)
 }
 
 // test hook: evaluates one device-side scalar function over arrays (rt_debug_eval)

@@ -123,13 +123,18 @@ static_assert(sizeof(Quad) == 144, "Quad must be 144 bytes");
 // Conservative f32 filter records for the quads of a flat leaf (rt_device_scene.h quad_pair_keep): one record per quad index i, holding
 // the pair (i, i + 1) interleaved — (value of quad i, value of quad i + 1) — so that one packed f32 instruction serves both; the
 // quad stage reads the records of its leaf's first, third, fifth ... quad.  Built by rt_qfilt.hpp (host), LDS-resident scenes only.
-//   [0..2] normal  [3] d  [4..6] A = v x w  [7] A.q + 1/2  [8..10] B = w x u  [11] B.q + 1/2
-//   [12] 14 * 2^-24 * |normal|_1 (+inf: never filter this quad)  [13] 14 * 2^-24 * |d|  [14] |A|_1  [15] 1/2 + K_alpha  [16] |B|_1  [17] 1/2 + K_beta
-// so that alpha - 1/2 = A . p - [7] and beta - 1/2 = B . p - [11] at the hit point p (src/quad.rs:117-127: alpha = w . (php x v) = php . (v x w)).
+//   v[0..2] normal  v[3] d  v[4..6] A = v x w  v[7] A.q + 1/2  v[8..10] B = w x u  v[11] B.q + 1/2
+// so that alpha - 1/2 = A . p - v[7] and beta - 1/2 = B . p - v[11] at the hit point p (src/quad.rs:117-127: alpha = w . (php x v) = php . (v x w)).
+// A quad that is never to be filtered has a NaN normal (every comparison against it is false: kept).  The error terms that go
+// with these values are the pair's: the larger of its two quads' (a leaf's quads are of one size).
 struct alignas(16) QFiltPair {
-    float v[18][2];
+    float v[12][2];
+    float n1c;  // 14 * 2^-24 * |normal|_1
+    float dc;   // 14 * 2^-24 * |d|
+    float a1;   // max(|A|_1, |B|_1)
+    float ka;   // 1/2 + K_alpha (resp. K_beta)
 };
-static_assert(sizeof(QFiltPair) == 144, "QFiltPair must be 144 bytes");
+static_assert(sizeof(QFiltPair) == 112, "QFiltPair must be 112 bytes");
 
 // One frame change: optional Translate (applied to the ray first) then optional RotateY, i.e. the reference's
 // Translate::hit -> RotateY::hit nesting (src/hittable.rs:96-106,:159-188).  parent = enclosing instance or -1.

@@ -14,7 +14,11 @@
 //     |a~ - (alpha - 1/2)| <= |A|_1 Ep + K_alpha,   K_alpha = 2^-20 (|A.q| + 1/2) + 2^-40 |A|_1 |q|_1  (+ the f64 side's own rounding)
 // The quad is dropped iff |dn| > Ed2 and one of  t~ + Et < tmin,  t~ - Et > tmax,  |a~| - |A|_1 Ep > 1/2 + K_alpha,  the same for b~
 // holds as a FINITE positive excess (an overflow anywhere gives inf - inf = NaN or an infinite bound: never a drop).
-// Quads whose constants leave [2^-40, 2^40] are never filtered (slot [12] = +inf makes Ed2 infinite).
+// The error terms |n|_1, |D|, |A|_1, K are those of the PAIR (the larger of its two quads', one value each): a flat leaf's quads are of
+// one size, the bounds stay a few 1e-6 of the unit square, and a record is 112 bytes instead of 144.
+// The same bounds also tell when alpha and beta are CERTAINLY inside [0, 1] (|a~| + bound <= 1/2): the exact test of such a survivor
+// need not evaluate them (its verdict on them is known), only its plane distance — two thirds of its arithmetic.
+// Quads whose constants leave [2^-40, 2^40] are never filtered (a NaN normal makes dn a NaN).
 #pragma once
 #include "rt_layout.h"
 
@@ -30,7 +34,9 @@ inline float qfilt_up(double x) { // a float not below x (x >= 0)
     return f;
 }
 
-inline void qfilt_fill(const Quad &q, QFiltPair &out, int slot) {
+// the quad's record values into `slot` of a pair record (zeroed by the caller), its error terms folded into the pair's (the larger
+// of the two); false (and a NaN normal in the slot: never filtered) for a quad whose constants leave the range the bounds are derived for
+inline bool qfilt_fill(const Quad &q, QFiltPair &out, int slot) {
     const double *u = q.u, *v = q.v, *w = q.w, *n = q.normal, *Q = q.q;
     const double A[3] = {v[1] * w[2] - v[2] * w[1], v[2] * w[0] - v[0] * w[2], v[0] * w[1] - v[1] * w[0]};
     const double B[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
@@ -40,22 +46,21 @@ inline void qfilt_fill(const Quad &q, QFiltPair &out, int slot) {
     const double big = 0x1p40, small = 0x1p-40, eps = 0x1p-24;
     const bool ok = n1 >= small && n1 <= big && A1 >= small && A1 <= big && B1 >= small && B1 <= big && std::fabs(q.d) <= big &&
                     std::fabs(AQ) <= big && std::fabs(BQ) <= big && Q1 <= big; // (false for a NaN anywhere)
-    float r[18] = {};
+    float r[12] = {};
     if (ok) {
         for (int k = 0; k < 3; ++k) { r[k] = (float)n[k]; r[4 + k] = (float)A[k]; r[8 + k] = (float)B[k]; }
         r[3] = (float)q.d;
         r[7] = (float)(AQ + 0.5);
         r[11] = (float)(BQ + 0.5);
-        r[12] = qfilt_up(14.0 * eps * n1);
-        r[13] = qfilt_up(14.0 * eps * std::fabs(q.d) + 0x1p-100);
-        r[14] = qfilt_up(A1 * (1.0 + 0x1p-20));
-        r[15] = qfilt_up(0.5 + 0x1p-20 * (std::fabs(AQ) + 0.5) + 0x1p-40 * A1 * Q1 + 0x1p-100);
-        r[16] = qfilt_up(B1 * (1.0 + 0x1p-20));
-        r[17] = qfilt_up(0.5 + 0x1p-20 * (std::fabs(BQ) + 0.5) + 0x1p-40 * B1 * Q1 + 0x1p-100);
+        out.n1c = std::fmax(out.n1c, qfilt_up(14.0 * eps * n1));
+        out.dc = std::fmax(out.dc, qfilt_up(14.0 * eps * std::fabs(q.d) + 0x1p-100));
+        out.a1 = std::fmax(out.a1, qfilt_up(std::fmax(A1, B1) * (1.0 + 0x1p-20)));
+        out.ka = std::fmax(out.ka, qfilt_up(0.5 + 0x1p-20 * (std::fmax(std::fabs(AQ), std::fabs(BQ)) + 0.5) + 0x1p-40 * std::fmax(A1, B1) * Q1 + 0x1p-100));
     } else {
-        r[12] = INFINITY; // Ed2 = inf (or NaN): the guard fails, the quad is always kept
+        r[0] = r[1] = r[2] = NAN; // dn is a NaN: the guard |dn| > Ed2 fails, the quad is always kept
     }
-    for (int k = 0; k < 18; ++k) out.v[k][slot] = r[k];
+    for (int k = 0; k < 12; ++k) out.v[k][slot] = r[k];
+    return ok;
 }
 
 // record i = the pair (quad i, quad i + 1); the last record's second slot is a quad that is never filtered (and never looked at:
@@ -66,7 +71,7 @@ inline std::vector<QFiltPair> qfilt_table(const std::vector<Quad> &quads) {
         std::memset(&t[i], 0, sizeof t[i]);
         qfilt_fill(quads[i], t[i], 0);
         if (i + 1 < quads.size()) qfilt_fill(quads[i + 1], t[i], 1);
-        else t[i].v[12][1] = INFINITY;
+        else t[i].v[0][1] = t[i].v[1][1] = t[i].v[2][1] = NAN;
     }
     return t;
 }

@@ -185,3 +185,71 @@ def test_gpu_render_matches_the_reference_screenshot_pixel_by_pixel(rt, gpu, nam
     print(name, {k: (v if not callable(v) else [round(v(t), 5) for t in (1.0, 2.0, 3.0)]) for k, v in st.items()})
     assert st["within"](3.0) >= 0.99, (st["within"](3.0), st["rms"])
     assert st["ref_edges"] > 1000 and st["ref_edges_found"] >= 0.99 and st["our_edges_found"] >= 0.99, st
+
+
+# ---- edge pins: checker.png / earth.png (src/main.rs:140-203), 1200x675, depth 8 -----------------------------------------------------
+# Both screenshots come from an older revision of the reference (gradient sky, texels without powf(2.2)): their shading pins nothing,
+# but where their edges are does — the checker's cell boundaries (CheckerTexture's scale and i32 parity, src/texture.rs:60-69), the
+# spheres' silhouettes, the continents' outlines (get_sphere_uv and the 1 - v flip, src/sphere.rs:48-52, src/texture.rs:83-92) and the
+# 16:9 / vfov-20 cameras.  Fixture tests/golden/reference_edge_pins.npz (tests/golden/make_reference_edge_pins.py): thin edge ridges.
+EDGE_PINS = np.load(Path(__file__).parent / "golden" / "reference_edge_pins.npz")
+
+
+def edge_pin_stats(rt, sums, spp, name, width=1200, height=675):
+    import sys
+    from scipy.ndimage import binary_dilation
+    sys.path.insert(0, str(Path(__file__).parent / "golden"))
+    from make_reference_edge_pins import ridges  # (the fixture's own definition of an edge ridge; reads nothing of the reference)
+    srgb = rt.resolve_rgb8_host(width, height, spp, sums).astype(np.float64)
+    hi, lo = float(EDGE_PINS["hi"]), float(EDGE_PINS["lo"])
+    unpack = lambda key: np.unpackbits(EDGE_PINS[f"{name}_{key}"])[:4 * width * height].reshape(4, height, width).astype(bool)
+    near = lambda m: np.stack([binary_dilation(x, structure=np.ones((3, 3), dtype=bool)) for x in m])
+    ours_strong, ours_weak, ref_strong, ref_weak = ridges(srgb, hi), ridges(srgb, lo), unpack("strong"), unpack("weak")
+    return {"ref_edges": int(ref_strong.sum()), "ref_edges_found": float((ref_strong & near(ours_weak)).sum() / ref_strong.sum()),
+            "our_edges": int(ours_strong.sum()), "our_edges_found": float((ours_strong & near(ref_weak)).sum() / max(1, ours_strong.sum()))}
+
+
+def edge_pin_scene(rt, name, spp):
+    kw = {"earth_image": str(ASSETS / "earth-large.jpg")} if name == "earth" else {}
+    hs = rt.HostScene(int(EDGE_PINS[f"{name}_scene"]), spp=spp, **kw)  # in-code cameras (src/main.rs:159-171, :190-202)
+    assert (hs.width, hs.height, hs.camera.max_depth) == (1200, 675, 8)
+    return hs
+
+
+@pytest.mark.parametrize("name,floor", [("checker", 0.999), ("earth", 0.99)])
+def test_oracle_puts_the_checker_and_earth_edges_where_the_reference_screenshots_have_them(rt, oracle, name, floor):
+    """24 spp of the oracle at the in-code camera: every strong edge ridge of the screenshot within one pixel of one of ours and the
+    other way round (checker: 36 000 ridge pixels, 100 %; earth: 2 800, 99.8 % — its coastlines are noisier at 24 spp)."""
+    spp = 24
+    hs = edge_pin_scene(rt, name, spp)
+    st = edge_pin_stats(rt, oracle.render(hs, rt.render_params(seed=7)), spp, name)
+    assert st["ref_edges"] > 2500 and st["ref_edges_found"] >= floor and st["our_edges_found"] >= floor, st
+
+
+def test_the_checker_edge_pin_bites(rt, oracle):
+    """What the pin would say to a slightly wrong CheckerTexture or camera: a scale of 0.325 instead of 0.32 (src/main.rs:149) loses
+    three quarters of the edges, a frame shifted by two pixels an eighth of them."""
+    spp = 8
+    hs = edge_pin_scene(rt, "checker", spp)
+    checkers = [i for i in range(hs.desc.n_textures) if hs.desc.textures[i].kind == rt.RT_TEXTURE_CHECKER]
+    assert len(checkers) == 1 and abs(hs.desc.textures[checkers[0]].inv_scale - 1.0 / 0.32) < 1e-12
+    hs.desc.textures[checkers[0]].inv_scale = 1.0 / 0.325
+    st = edge_pin_stats(rt, oracle.render(hs, rt.render_params(seed=7)), spp, "checker")
+    assert st["ref_edges_found"] < 0.5 and st["our_edges_found"] < 0.5, st
+    hs = edge_pin_scene(rt, "checker", spp)
+    cam = hs.camera
+    for ax in "xyz":
+        setattr(cam.pixel00_loc, ax, getattr(cam.pixel00_loc, ax) + 2.0 * getattr(cam.pixel_delta_u, ax))
+    st = edge_pin_stats(rt, oracle.render(hs, rt.render_params(seed=7)), spp, "checker")
+    assert st["ref_edges_found"] < 0.95 and st["our_edges_found"] < 0.95, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["checker", "earth"])
+def test_gpu_render_puts_the_checker_and_earth_edges_where_the_reference_screenshots_have_them(rt, gpu, name):
+    """1024 spp at the in-code camera on the GPU (whose frame equals the oracle's bit for bit): the same pin without the noise."""
+    spp = 1024
+    hs = edge_pin_scene(rt, name, spp)
+    st = edge_pin_stats(rt, rt.DeviceScene(hs).render(rt.render_params(seed=7)), spp, name)
+    print(name, st)
+    assert st["ref_edges"] > 2500 and st["ref_edges_found"] >= 0.995 and st["our_edges_found"] >= 0.995, st
