@@ -253,3 +253,51 @@ def test_gpu_render_puts_the_checker_and_earth_edges_where_the_reference_screens
     st = edge_pin_stats(rt, rt.DeviceScene(hs).render(rt.render_params(seed=7)), spp, name)
     print(name, st)
     assert st["ref_edges"] > 2500 and st["ref_edges_found"] >= 0.995 and st["our_edges_found"] >= 0.995, st
+
+
+# ---- the defocus disk (src/camera.rs:97-99,:128-131): no reference artefact pins it ---------------------------------------------------
+# screenshots/random_balls.png — the one screenshot of the one scene with defocus_angle > 0 — was rendered by an older revision from
+# another camera: the ground fills the lower 60 % of its frame and the three unit spheres sit in rows 75-350, columns 400-1000, where
+# the committed camera (src/main.rs:121-135: from (13,2,3), vfov 20) puts the nearest of them at rows 50-460.  No edge of it can be laid
+# over a render of the committed code, so there is nothing to measure a blur width against.  What CAN be held to the reference is its
+# source's thin-lens geometry, as a known-answer test: defocus radius R = focus_dist * tan(defocus_angle / 2) on the lens, so an
+# edge at depth D is smeared over a disk of diameter 2 R |D - f| / D on the focus plane (a uniform disk across a straight edge:
+# 10-90 % width = 0.687 diameters), on top of the 2.7 pixels the in-focus edge shows (pixel footprint + the 3-tap smoothing below).
+@pytest.mark.gpu
+def test_defocus_blur_of_random_balls_has_the_thin_lens_width(rt, gpu):
+    from scipy.ndimage import uniform_filter1d
+    spp = 256
+    hs = rt.HostScene(0, width=1200, spp=spp, depth=8)   # the in-code camera at twice the in-code width: 1200 x 675
+    assert (hs.width, hs.height) == (1200, 675) and abs(hs.camera.defocus_angle - 0.6) < 1e-12
+    srgb = rt.resolve_rgb8_host(1200, 675, spp, rt.DeviceScene(hs).render(rt.render_params(seed=7))).astype(np.float64).reshape(675, 1200, 3)
+    lum = srgb @ np.array([0.2126, 0.7152, 0.0722])
+    cam = hs.camera
+    vec = lambda v: np.array([v.x, v.y, v.z])
+    c, p00, du, dv = vec(cam.center), vec(cam.pixel00_loc), vec(cam.pixel_delta_u), vec(cam.pixel_delta_v)
+
+    def project(p):  # pixel coordinates of a world point: p00 + i du + j dv = c + s (p - c)
+        x = np.linalg.solve(np.stack([du, dv, -(p - c)], axis=1), c - p00)
+        return x[0], x[1]
+
+    def top_edge_width(centre):  # median 10-90 % width of the sphere's upper silhouette (sky above it) over 16 columns
+        ci, cj = project(np.array(centre, dtype=float))
+        _, jt = project(np.array(centre, dtype=float) + np.array([0.0, 1.0, 0.0]))
+        rad = cj - jt
+        widths = []
+        for di in range(-30, 31, 4):
+            i = int(round(ci + di))
+            j0 = int(cj - np.sqrt(rad * rad - di * di))
+            p = uniform_filter1d(lum[j0 - 22:j0 + 23, i - 2:i + 3].mean(axis=1), 3)
+            q = (p - p[:6].mean()) / (p[-6:].mean() - p[:6].mean())
+            cross = lambda lv: next(k + (lv - q[k]) / (q[k + 1] - q[k]) for k in range(len(q) - 1) if (q[k] - lv) * (q[k + 1] - lv) <= 0)
+            widths.append(cross(0.9) - cross(0.1))
+        return float(np.median(widths))
+
+    focus, f_px = 10.0, np.linalg.norm(du)  # focus_dist (src/main.rs:133); the viewport lies on the focus plane: one pixel = |du| there
+    lens_radius = focus * np.tan(np.radians(0.6) / 2.0)
+    in_focus = top_edge_width((4.0, 1.0, 0.0))   # the metal sphere, 9.5 from the camera: half a pixel of blur
+    far = top_edge_width((-4.0, 1.0, 0.0))       # the brown sphere, 17.3 away
+    depth = np.linalg.norm(np.array([-4.0, 2.0, 0.0]) - c)
+    predicted = np.hypot(0.687 * 2.0 * lens_radius * abs(depth - focus) / depth / f_px, in_focus)
+    print("edge widths in pixels: in focus", in_focus, "far", far, "thin lens predicts", predicted)
+    assert in_focus < 3.5 and abs(far / predicted - 1.0) < 0.2, (in_focus, far, predicted)
