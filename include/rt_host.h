@@ -26,7 +26,7 @@ typedef struct rth_scene_options {
     double aspect_ratio;       /* <= 0: the scene's in-code value                                        */
     int32_t samples_per_pixel; /* <= 0: the scene's in-code value                                        */
     int32_t max_depth;         /* <= 0: the scene's in-code value                                        */
-    const char *earth_image;   /* NULL: "synthetic:1024x512"; else a path (PPM/JPEG) or "synthetic:WxH"  */
+    const char *earth_image;   /* NULL: "synthetic:1024x512"; else a path (PPM, baseline JPEG, 8-bit PNG) or "synthetic:WxH"  */
 } rth_scene_options;
 
 /* Builds scene + top-level BVH + camera exactly as `main` does (src/main.rs:645-660) and describes them. */

@@ -101,6 +101,101 @@ static ImageRGB8 load_ppm(const std::string &path, FILE *f) {
     return img;
 }
 
+static inline int paeth_predictor(int a, int b, int c) {
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// PNG (ISO 15948), non-interlaced, 8 bits per channel: grey, grey + alpha, RGB, palette, RGBA.  The reference reads a texel with
+// DynamicImage::get_pixel (src/texture.rs:89), i.e. as RGBA8 whatever the file holds: grey is replicated, a palette looked up, alpha
+// dropped ([r, g, b, _]).  16-bit samples and Adam7 interlacing are refused with a message rather than guessed at.
+static ImageRGB8 decode_png(const std::string &path, const std::vector<uint8_t> &file) {
+    auto fail = [&](const char *what) -> ImageRGB8 { throw std::runtime_error("load_image_rgb8: " + path + ": PNG: " + what); };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8) != 0) return fail("bad signature");
+    auto be32 = [&](size_t at) { return ((uint32_t)file[at] << 24) | ((uint32_t)file[at + 1] << 16) | ((uint32_t)file[at + 2] << 8) | file[at + 3]; };
+    uint32_t width = 0, height = 0;
+    int depth = 0, colour = -1, interlace = 0;
+    std::vector<uint8_t> idat, palette;
+    bool seen_end = false;
+    for (size_t at = 8; at + 12 <= file.size() && !seen_end;) {
+        const uint32_t len = be32(at);
+        if ((uint64_t)at + 12u + len > file.size()) return fail("truncated chunk");
+        const char *type = reinterpret_cast<const char *>(file.data() + at + 4);
+        const uint8_t *data = file.data() + at + 8;
+        if ((uint32_t)crc32(0L, file.data() + at + 4, (uInt)(len + 4)) != be32(at + 8 + len)) return fail("chunk CRC mismatch");
+        if (memcmp(type, "IHDR", 4) == 0) {
+            if (len != 13) return fail("bad IHDR");
+            width = be32(at + 8); height = be32(at + 12);
+            depth = data[8]; colour = data[9]; interlace = data[12];
+            if (data[10] != 0 || data[11] != 0) return fail("unknown compression or filter method");
+        } else if (memcmp(type, "PLTE", 4) == 0) {
+            palette.assign(data, data + len);
+        } else if (memcmp(type, "IDAT", 4) == 0) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (memcmp(type, "IEND", 4) == 0) {
+            seen_end = true;
+        }
+        at += 12u + (size_t)len;
+    }
+    if (colour < 0 || width == 0 || height == 0 || width > 65535u || height > 65535u) return fail("missing or bad IHDR");
+    if (interlace != 0) return fail("Adam7-interlaced files are not supported");
+    if (depth != 8) return fail("only 8 bits per sample are supported");
+    int channels = 0;
+    switch (colour) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; if (palette.size() < 3 || palette.size() % 3 != 0) return fail("palette image without a PLTE chunk"); break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: return fail("unknown colour type");
+    }
+    const size_t stride = (size_t)width * (size_t)channels;
+    std::vector<uint8_t> raw((stride + 1u) * (size_t)height);
+    uLongf raw_len = (uLongf)raw.size();
+    const int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+    if (zrc != Z_OK || raw_len != raw.size()) return fail("image data does not inflate to the size IHDR announces");
+    // undo the per-row filters in place (ISO 15948 section 9)
+    std::vector<uint8_t> zero(stride, 0);
+    for (uint32_t y = 0; y < height; ++y) {
+        uint8_t *row = raw.data() + (size_t)y * (stride + 1u);
+        const int filter = row[0];
+        uint8_t *cur = row + 1;
+        const uint8_t *up = y ? row - stride : zero.data();
+        if (filter < 0 || filter > 4) return fail("unknown row filter");
+        for (size_t x = 0; x < stride; ++x) {
+            const int a = x >= (size_t)channels ? cur[x - (size_t)channels] : 0, b = up[x], c = x >= (size_t)channels ? up[x - (size_t)channels] : 0;
+            int v = cur[x];
+            switch (filter) {
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth_predictor(a, b, c); break;
+            default: break;
+            }
+            cur[x] = (uint8_t)v;
+        }
+    }
+    auto px = std::make_shared<std::vector<uint8_t>>((size_t)width * (size_t)height * 3u);
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint8_t *cur = raw.data() + (size_t)y * (stride + 1u) + 1u;
+        uint8_t *dst = px->data() + (size_t)y * (size_t)width * 3u;
+        for (uint32_t x = 0; x < width; ++x) {
+            const uint8_t *sp = cur + (size_t)x * (size_t)channels;
+            uint8_t r, g, b;
+            if (colour == 0 || colour == 4) { r = g = b = sp[0]; }
+            else if (colour == 3) {
+                if ((size_t)sp[0] * 3u + 2u >= palette.size()) return fail("palette index out of range");
+                r = palette[(size_t)sp[0] * 3u]; g = palette[(size_t)sp[0] * 3u + 1u]; b = palette[(size_t)sp[0] * 3u + 2u];
+            } else { r = sp[0]; g = sp[1]; b = sp[2]; }
+            dst[x * 3u] = r; dst[x * 3u + 1u] = g; dst[x * 3u + 2u] = b;
+        }
+    }
+    ImageRGB8 img;
+    img.width = (int32_t)width; img.height = (int32_t)height; img.pixels = px;
+    return img;
+}
+
 ImageRGB8 load_image_rgb8(const std::string &path) {
     if (path.rfind("synthetic:", 0) == 0) {
         int w = 0, h = 0;
@@ -117,7 +212,7 @@ ImageRGB8 load_image_rgb8(const std::string &path) {
         ImageRGB8 img;
         if (n == 2 && head[0] == 'P' && head[1] == '6') {
             img = load_ppm(path, f);
-        } else if (n == 2 && head[0] == 0xFF && head[1] == 0xD8) {
+        } else if (n == 2 && ((head[0] == 0xFF && head[1] == 0xD8) || (head[0] == 0x89 && head[1] == 'P'))) {
             std::vector<uint8_t> bytes;
             fseek(f, 0, SEEK_END);
             long sz = ftell(f);
@@ -125,9 +220,9 @@ ImageRGB8 load_image_rgb8(const std::string &path) {
             bytes.resize((size_t)sz);
             if (fread(bytes.data(), 1, bytes.size(), f) != bytes.size())
                 throw std::runtime_error("load_image_rgb8: short read on " + path);
-            img = decode_baseline_jpeg(bytes.data(), bytes.size());
+            img = head[0] == 0xFF ? decode_baseline_jpeg(bytes.data(), bytes.size()) : decode_png(path, bytes);
         } else {
-            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6 or baseline JPEG)");
+            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6, baseline JPEG or 8-bit PNG)");
         }
         fclose(f);
         return img;
@@ -149,10 +244,7 @@ static void put_chunk(std::vector<uint8_t> &out, const char type[4], const uint8
     uint32_t crc = (uint32_t)crc32(0L, out.data() + start, (uInt)(len + 4));
     put_u32(out, crc);
 }
-static inline int paeth(int a, int b, int c) {
-    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-}
+static inline int paeth(int a, int b, int c) { return paeth_predictor(a, b, c); }
 
 bool write_png_rgb8(const std::string &path, int32_t width, int32_t height, const uint8_t *rgb) {
     if (width <= 0 || height <= 0 || !rgb) return false;

@@ -213,3 +213,45 @@ def test_jpeg_decoder_matches_pillow(rt, tmp_path):
     Image.fromarray(img).save(tmp_path / "earth.jpg", "JPEG", quality=90)
     hs = rt.HostScene(2, spp=1, earth_image=str(tmp_path / "earth.jpg"))
     assert (hs.desc.images[0].width, hs.desc.images[0].height) == (W, H)
+
+
+def test_png_reader_matches_pillow(rt, tmp_path):
+    """ImageTexture ingest of PNG files (the reference opens any format the `image` crate knows, src/texture.rs:78, and reads texels as
+    RGBA8 through get_pixel: grey replicated, palettes looked up, alpha dropped): grey, grey + alpha, RGB, RGBA and palette images come
+    out as Pillow's convert("RGB") has them; the library's own PNG writer round-trips; what is not supported is refused by name."""
+    from PIL import Image
+    lib = rt.host_lib()
+    rng = np.random.default_rng(5)
+    H, W = 37, 53
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    rgb[5:20, 7:30] = (200, 30, 90)  # a flat patch: rows where the Sub / Up / Paeth filters get picked
+
+    def load(path):
+        w, h = C.c_int32(), C.c_int32()
+        assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0) == 0, lib.rth_last_error()
+        got = np.zeros(w.value * h.value * 3, dtype=np.uint8)
+        assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), got.ctypes.data_as(C.POINTER(C.c_uint8)), got.size) == 0
+        return got.reshape(h.value, w.value, 3)
+
+    images = {"rgb": Image.fromarray(rgb), "rgba": Image.fromarray(np.dstack([rgb, rng.integers(0, 256, (H, W), dtype=np.uint8)])),
+              "grey": Image.fromarray(rgb[:, :, 0]), "grey_alpha": Image.fromarray(np.dstack([rgb[:, :, 0], rgb[:, :, 1]]), "LA"),
+              "palette": Image.fromarray(rgb).quantize(64)}
+    for name, im in images.items():
+        path = tmp_path / f"{name}.png"
+        im.save(path, "PNG", optimize=(name == "rgb"))
+        assert np.array_equal(load(path), np.asarray(Image.open(path).convert("RGB"))), name
+    # the library's own writer (adaptive filters) and its reader are inverses
+    own = tmp_path / "own.png"
+    assert lib.rth_write_png(str(own).encode(), W, H, np.ascontiguousarray(rgb).ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert np.array_equal(load(own), rgb) and np.array_equal(np.asarray(Image.open(own).convert("RGB")), rgb)
+    # refused, with the reason: 16 bits per sample, interlacing, a damaged file
+    Image.fromarray((rgb[:, :, 0].astype(np.uint16) << 8)).save(tmp_path / "deep.png")
+    Image.fromarray(rgb).save(tmp_path / "adam7.png", "PNG", interlace=True) if hasattr(Image, "ADAPTIVE") else None
+    w, h = C.c_int32(), C.c_int32()
+    assert lib.rth_load_image(str(tmp_path / "deep.png").encode(), C.byref(w), C.byref(h), None, 0) != 0 and b"8 bits" in lib.rth_last_error()
+    damaged = bytearray((tmp_path / "rgb.png").read_bytes()); damaged[60] ^= 0x40
+    (tmp_path / "damaged.png").write_bytes(bytes(damaged))
+    assert lib.rth_load_image(str(tmp_path / "damaged.png").encode(), C.byref(w), C.byref(h), None, 0) != 0 and b"PNG" in lib.rth_last_error()
+    # ... and a PNG texture reaches the scene description like a JPEG does
+    hs = rt.HostScene(2, spp=1, earth_image=str(tmp_path / "rgb.png"))
+    assert (hs.desc.images[0].width, hs.desc.images[0].height) == (W, H)
