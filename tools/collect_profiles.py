@@ -118,3 +118,5 @@ if (SRC / "timeline_c4.txt").exists():
     shutil.copy(SRC / "timeline_c4.txt", DST / f"{tag}_c4_timeline.txt")
 if (SRC / "kernel_usage.txt").exists():
     shutil.copy(SRC / "kernel_usage.txt", DST / f"{tag}_kernel_usage.txt")
+if (SRC / "scene_speed.txt").exists():
+    shutil.copy(SRC / "scene_speed.txt", DST / f"{tag}_scene_speed.txt")
