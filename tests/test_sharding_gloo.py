@@ -78,5 +78,5 @@ def test_bench_starts_its_own_ranks_when_asked_for_more_than_one_gpu(rt):
                         "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
     assert r.returncode != 0
     # (the launcher stops the other rank as soon as one has failed: the message appears once or twice)
-    assert "no HIP device for this rank" in r.stderr and "ChildFailedError" in r.stderr, r.stderr[-1500:]
+    assert "bench.py rank" in r.stderr and "no HIP device for local rank 0" in r.stderr and "ChildFailedError" in r.stderr, r.stderr[-1500:]
     assert "must be launched with" not in r.stderr
