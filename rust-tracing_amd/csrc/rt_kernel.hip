@@ -767,7 +767,18 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     refresh_ray32();
                     a = len2(d);
                     if (leaving) o_next(false, 0u);
-                    else { node = inst_tab[cur_inst].root | W_FULL; stage = ST_BOX; }
+                    else {
+                        // (a frame whose tree is one leaf — a box's faces: straight to the leaf's primitives; the frame's box has been tested
+                        // where the walk met the instance, and what ends the leaf pops the stack as any leaf does)
+                        const uint32_t start = P.inst_shortcut != 0u ? inst_tab[cur_inst].start_ref : 0u;
+                        node = inst_tab[cur_inst].root | W_FULL;
+                        stage = ST_BOX;
+                        if (start != 0u) {
+                            stage = start >> OREF_KIND_SHIFT; // (OrderedKind SPHERES / QUADS = Stage ST_SPHERE / ST_QUAD)
+                            prim_cur = start & OREF_INDEX_MASK;
+                            prim_end = prim_cur + ((start >> OREF_COUNT_SHIFT) & OREF_COUNT_MASK) + 1u;
+                        }
+                    }
                 }
             } else
             if (stage == ST_OTHER) {

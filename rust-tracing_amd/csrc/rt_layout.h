@@ -145,7 +145,9 @@ struct alignas(64) Instance {
     uint32_t flags; // bit 0: has translate, bit 1: has rotate
     uint32_t depth; // 0 for an instance in the world frame
     uint32_t root;  // ordered layout: the root record of the tree over this frame's contents
-    uint32_t _pad[2];
+    uint32_t start_ref; // ordered layout: != 0: that root holds nothing but ONE leaf (a box's six faces): its reference — a walk that enters
+                        // the frame starts in the leaf's primitive stage, not with a visit of a record that has one thing to say
+    uint32_t _pad;
 };
 static_assert(sizeof(Instance) == 64, "Instance must be 64 bytes");
 constexpr uint32_t INST_TRANSLATE = 1u, INST_ROTATE = 2u;
