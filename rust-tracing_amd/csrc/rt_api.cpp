@@ -484,7 +484,7 @@ int resolve_scene_options(const rt_scene_options *options, rt_scene_options &opt
 extern "C" {
 
 const char *rt_last_error(void) { return g_last_error.c_str(); }
-const char *rt_version(void) { return "rt_amd 0.2 (gfx950, abi 2)"; }
+const char *rt_version(void) { return "rt_amd 0.4 (gfx950, abi 2: rt_scene_options grew to 88 bytes, older sizes accepted)"; }
 
 int rt_device_count(void) {
     int n = 0;

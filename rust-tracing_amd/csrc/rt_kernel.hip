@@ -764,13 +764,15 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                             sp++;
                         }
                     }
-                    refresh_ray32();
+                    // (a frame whose tree is one leaf — a box's faces: straight to the leaf's primitives; the frame's box has been tested
+                    // where the walk met the instance, and what ends the leaf pops the stack as any leaf does.  Such a walk tests no box
+                    // inside the frame — its next box test, if any, comes after the next frame change — so the ray's f32 copy is not
+                    // rebuilt for it.)
+                    const uint32_t start = (!leaving && P.inst_shortcut != 0u) ? inst_tab[cur_inst].start_ref : 0u;
+                    if (start == 0u) refresh_ray32();
                     a = len2(d);
                     if (leaving) o_next(false, 0u);
                     else {
-                        // (a frame whose tree is one leaf — a box's faces: straight to the leaf's primitives; the frame's box has been tested
-                        // where the walk met the instance, and what ends the leaf pops the stack as any leaf does)
-                        const uint32_t start = P.inst_shortcut != 0u ? inst_tab[cur_inst].start_ref : 0u;
                         node = inst_tab[cur_inst].root | W_FULL;
                         stage = ST_BOX;
                         if (start != 0u) {
