@@ -768,7 +768,10 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // where the walk met the instance, and what ends the leaf pops the stack as any leaf does.  Such a walk tests no box
                     // inside the frame — its next box test, if any, comes after the next frame change — so the ray's f32 copy is not
                     // rebuilt for it.)
-                    const uint32_t start = (!leaving && P.inst_shortcut != 0u) ? inst_tab[cur_inst].start_ref : 0u;
+                    // (LDS-resident scenes without media only: in the kernel that gathers final_scene from global memory — whose one instance
+                    // holds a tree of a thousand spheres — the mere presence of this branch cost 3 %, and cornell_smoke's kernel, where it
+                    // applies, lost 2.8 % with it)
+                    const uint32_t start = (LDS == 3 && !HAS_MEDIA && !leaving && P.inst_shortcut != 0u) ? inst_tab[cur_inst].start_ref : 0u;
                     if (start == 0u) refresh_ray32();
                     a = len2(d);
                     if (leaving) o_next(false, 0u);
