@@ -26,7 +26,7 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
-    env("RT_WIDE", wide); env("RT_QUAD_FILTER", quad_filter); env("RT_SAMPLE_TRIES", sample_tries);
+    env("RT_WIDE", wide); env("RT_QUAD_FILTER", quad_filter);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_FLAT_MAX")) ordered_options.flat_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
@@ -372,12 +372,6 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
-    // the unit-sphere rejection sample draws at most five candidates per shade round in the LDS-resident kernels that walk the library's own
-    // trees (same box, tries 0 / 5, Msamples/s: random_balls 4491 / 4530, two_spheres 8150 / 8268, two_perlin_spheres 4848 / 4980, cornell_box
-    // 3776 / 3861, C3 2622 / 2669 — 2680 at four); not where a scene is one textured sphere walked in reference order (earth 20990 / 18700), nor with
-    // media or from global memory (cornell_smoke 1633 / 1633, final_scene 1189 / 1175 at four)
-    K.inst_shortcut = tn.start_shortcut ? 1u : 0u;
-    K.sample_tries = tn.sample_tries >= 0 ? (uint32_t)tn.sample_tries : ((scene->ordered && lds == 3 && (scene->features & F_MEDIA) == 0u) ? 5u : 0u);
     K.slow_min = (uint32_t)tn.slow_min; K.slow_age = (uint32_t)tn.slow_age;
     K.o_start_stage = tn.start_shortcut ? scene->o_start_stage : 0u; K.o_start_prim = scene->o_start_prim; K.o_start_end = scene->o_start_end;
     K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;

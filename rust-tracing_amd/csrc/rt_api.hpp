@@ -82,7 +82,6 @@ struct Tuning {
                      // (ordered_walk_pays), 2 the ordered walk wherever the scene allows it
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     int wide = -1;         // own trees with four-child records (rt_layout.h ONode4): 1 always, 0 never, -1 for scenes of 64 primitives or more (RT_WIDE)
-    int sample_tries = -1; // KParams::sample_tries: -1 where it measured faster (launch_render), else this many, 0 = never defer (RT_SAMPLE_TRIES)
     int quad_filter = 1;   // multi-quad leaves go through the conservative f32 filter before the exact test (RT_QUAD_FILTER; rt_scene_options.quad_filter)
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
     int slow_min = 4, slow_age = 32; // KParams::slow_min / slow_age (RT_SLOW_MIN, RT_SLOW_AGE; slow_min 1: nobody waits)

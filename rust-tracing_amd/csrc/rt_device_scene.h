@@ -70,19 +70,6 @@ template <bool COUNT> RT_DEV V3 random_in_unit_sphere(Rng &rng, Counts &cn) {
         if (len2(p) < 1.0) return p;
     }
 }
-// ... at most `tries` candidates (0: as many as it takes): false if none was accepted yet.  The rejection loop has no memory, so a lane
-// that comes back later and draws on from where its stream stands ends with the candidate the unbounded loop would have ended with.
-template <bool COUNT> RT_DEV bool random_in_unit_sphere_bounded(Rng &rng, Counts &cn, uint32_t tries, V3 &out) {
-    for (uint32_t k = 0; tries == 0u || k < tries; ++k) {
-        const double x = rng.range(-1.0, 1.0);
-        const double y = rng.range(-1.0, 1.0);
-        const double z = rng.range(-1.0, 1.0);
-        if (COUNT) cn.rng_draws += 3;
-        const V3 p = v3(x, y, z);
-        if (len2(p) < 1.0) { out = p; return true; }
-    }
-    return false;
-}
 template <bool COUNT> RT_DEV V3 random_unit_vector(Rng &rng, Counts &cn) {
     return normalize(random_in_unit_sphere<COUNT>(rng, cn));
 }

@@ -904,14 +904,8 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 V3 tex = v3(1.0, 1.0, 1.0);
                 V3 rs = v3(0.0, 0.0, 0.0);
                 PROF_MARK(6);
-                // The wave runs the rejection loop until its LAST lane has a candidate inside the sphere — six or seven passes for forty lanes,
-                // the last three for a handful of them.  A lane still without one after sample_tries candidates stays queued for the shade
-                // stage and draws on in the next shade round (its stream stands where it left it; the hit is rebuilt: it depends on nothing
-                // that has changed).
-                bool sampled = true;
-                if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) sampled = random_in_unit_sphere_bounded<COUNT>(rng, cn, P.sample_tries, rs);
+                if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_DIFFUSE_LIGHT) rs = random_in_unit_sphere<COUNT>(rng, cn);
                 PROF_MARK(7);
-                if (sampled) {
                 if (mk != RT_MATERIAL_DIELECTRIC && mk != RT_MATERIAL_METAL) {
                     if constexpr (HAS_TEXTURES) tex = m->solid ? ld3(m->albedo) : texture_value<COUNT>(P, texs_tab, perlin_tab, m->texture, u, v, p, cn);
                     else tex = ld3(m->albedo); // every texture is a SolidColor (src/texture.rs:32-36): the colour was copied here
@@ -977,7 +971,6 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                 } else {
                     start_query = true; // of the scattered ray
                 }
-                } // (sampled)
                 } // (!postpone)
             }
         }

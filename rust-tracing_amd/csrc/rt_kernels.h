@@ -81,7 +81,6 @@ struct KParams {
     // leaf's kind (ST_SPHERE / ST_QUAD; 0: no shortcut), its primitives [prim, end), the root's other child, which child of the root the leaf is
     uint32_t o_start_stage, o_start_prim, o_start_end, o_start_rest, o_start_slot;
     uint32_t inst_shortcut;         // 1: a walk that enters a frame whose tree is one leaf starts with the leaf's primitives (Instance::start_ref)
-    uint32_t sample_tries;          // shade stage: candidates of the unit-sphere rejection sample a lane draws per round (0: until one is accepted)
     uint32_t slow_min, slow_age;    // shade stage: lanes with a dear texture wait for this many of their kind, at most this many shade rounds
     uint32_t seq_lookahead;         // 1: a query that cannot reach any later step of the world's sequence ends it at its start (path_kernel)
     uint32_t lds_stack_off;
