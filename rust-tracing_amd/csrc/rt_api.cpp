@@ -372,6 +372,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
+    K.inst_shortcut = tn.start_shortcut ? 1u : 0u;
     K.slow_min = (uint32_t)tn.slow_min; K.slow_age = (uint32_t)tn.slow_age;
     K.o_start_stage = tn.start_shortcut ? scene->o_start_stage : 0u; K.o_start_prim = scene->o_start_prim; K.o_start_end = scene->o_start_end;
     K.o_start_rest = scene->o_start_rest; K.o_start_slot = scene->o_start_slot;
