@@ -1006,10 +1006,15 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         uint32_t level = n_att > IDS_IN_REGS ? n_att - IDS_IN_REGS : 0u; // levels [0, level) are in att_ids
                         while (level > 0) {
                             V3 parked[CHAIN];
+                            // (the loads are unconditional — a level the path does not have reads its level 0 and drops the value —:
+                            // behind `level > j ? load : id_one` each became a branch with its own wait, CHAIN memory latencies in a row)
+                            uint32_t stored[CHAIN];
+                    #pragma unroll
+                            for (uint32_t j = 0; j < CHAIN; ++j) stored[j] = att_ids[(level > j ? level - 1u - j : 0u) * att_lanes + gtid];
                     #pragma unroll
                             for (uint32_t j = 0; j < CHAIN; ++j) {
                                 const uint32_t lv = level > j ? level - 1u - j : 0u;
-                                const uint32_t id = level > j ? att_ids[lv * att_lanes + gtid] : P.id_one;
+                                const uint32_t id = level > j ? stored[j] : P.id_one;
                                 parked[j] = parked_colour(id, lv);
                             }
                     #pragma unroll
