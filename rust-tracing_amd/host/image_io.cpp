@@ -220,9 +220,9 @@ ImageRGB8 load_image_rgb8(const std::string &path) {
             bytes.resize((size_t)sz);
             if (fread(bytes.data(), 1, bytes.size(), f) != bytes.size())
                 throw std::runtime_error("load_image_rgb8: short read on " + path);
-            img = head[0] == 0xFF ? decode_baseline_jpeg(bytes.data(), bytes.size()) : decode_png(path, bytes);
+            img = head[0] == 0xFF ? decode_jpeg(bytes.data(), bytes.size()) : decode_png(path, bytes);
         } else {
-            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6, baseline JPEG or 8-bit PNG)");
+            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6, JPEG or 8-bit PNG)");
         }
         fclose(f);
         return img;

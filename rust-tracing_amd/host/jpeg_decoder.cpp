@@ -1,4 +1,5 @@
-// Baseline JPEG decoder (ITU T.81 sequential DCT, Huffman, 8-bit) for ImageTexture ingest.
+// JPEG decoder (ITU T.81, Huffman, 8-bit: baseline / extended sequential DCT in one or several scans, and progressive DCT —
+// spectral selection and successive approximation, Annex G) for ImageTexture ingest.
 //
 // The reference decodes its texture with the `image` crate (src/texture.rs:78).  Decoder output is not part of any
 // contract the reference states (decoders differ by +-1 level on chroma-subsampled files), so this one follows the
@@ -15,7 +16,7 @@
 namespace rt {
 namespace {
 
-[[noreturn]] void bad(const std::string &m) { throw std::runtime_error("decode_baseline_jpeg: " + m); }
+[[noreturn]] void bad(const std::string &m) { throw std::runtime_error("decode_jpeg: " + m); }
 
 const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -55,6 +56,9 @@ struct Component {
     int blocks_w = 0, blocks_h = 0; // allocated size in 8x8 blocks (padded to whole MCUs)
     int width = 0, height = 0;      // real (downsampled) size in samples
     int pred = 0;
+    std::vector<int16_t> coefs;     // blocks_w x blocks_h blocks of 64 coefficients (natural order), as the scans leave them: quantised
+    uint16_t qt[64];                // the component's quantisation table, latched at its first scan (a file may redefine a slot later)
+    bool qt_latched = false;
     std::vector<uint8_t> plane;     // blocks_w*8 x blocks_h*8 samples
 };
 
@@ -63,25 +67,30 @@ struct BitReader {
     uint32_t acc = 0;
     int bits = 0;
     bool hit_marker = false;
+    int made_up = 0; // bits at the low end of the accumulator that no byte of the file stands behind (fed after a marker or the end)
 
     void fill() {
         while (bits <= 24) {
             int byte = 0;
+            bool real = false;
             if (!hit_marker && p < end) {
                 byte = *p++;
+                real = true;
                 if (byte == 0xFF) {
                     if (p < end && *p == 0x00) { ++p; }             // stuffed zero
-                    else { hit_marker = true; --p; byte = 0; }      // a marker: feed zeros from here on
+                    else { hit_marker = true; --p; byte = 0; real = false; } // a marker: feed zeros from here on
                 }
             }
+            if (!real) made_up += 8;
             acc |= (uint32_t)byte << (24 - bits);
             bits += 8;
         }
     }
+    bool overran() const { return bits < made_up; } // the decoder has consumed bits the file does not hold
     int peek(int n) { if (bits < n) fill(); return (int)(acc >> (32 - n)); }
     void skip(int n) { acc <<= n; bits -= n; }
     int get(int n) { if (n == 0) return 0; int v = peek(n); skip(n); return v; }
-    void reset() { acc = 0; bits = 0; hit_marker = false; }
+    void reset() { acc = 0; bits = 0; hit_marker = false; made_up = 0; }
 };
 
 int decode_symbol(BitReader &br, const HuffTable &t) {
@@ -167,8 +176,9 @@ struct Decoder {
     bool quant_present[4] = {false, false, false, false};
     HuffTable dc[4], ac[4];
     std::vector<Component> comps;
-    bool have_frame = false;
+    bool have_frame = false, progressive = false;
     int adobe_transform = -1;
+    uint32_t eobrun = 0; // progressive AC scans: blocks still covered by the last end-of-band run
 
     Decoder(const uint8_t *d, size_t n) : data(d), size(n) {}
 
@@ -221,19 +231,21 @@ struct Decoder {
             c.blocks_w = mcus_x * c.h; c.blocks_h = mcus_y * c.v;
             c.width = (width * c.h + max_h - 1) / max_h; c.height = (height * c.v + max_v - 1) / max_v;
             c.plane.assign((size_t)c.blocks_w * 8 * (size_t)c.blocks_h * 8, 0);
+            c.coefs.assign((size_t)c.blocks_w * (size_t)c.blocks_h * 64, 0);
         }
         have_frame = true;
     }
 
-    void decode_block(BitReader &br, Component &c, int bx, int by) {
+    int16_t *block_of(Component &c, int bx, int by) { return c.coefs.data() + ((size_t)by * c.blocks_w + (size_t)bx) * 64; }
+
+    // One block of a sequential scan (T.81 F.2.2): DC difference, then (run, size) pairs up to the end of block
+    void block_sequential(BitReader &br, Component &c, int16_t *blk) {
         const HuffTable &hd = dc[c.td], &ha = ac[c.ta];
-        if (!hd.present || !ha.present || !quant_present[c.tq]) bad("missing table");
-        int32_t coef[64] = {0};
+        if (!hd.present || !ha.present) bad("missing table");
         int t = decode_symbol(br, hd);
         if (t > 11) bad("bad DC size");
-        int diff = t ? extend(br.get(t), t) : 0;
-        c.pred += diff;
-        coef[0] = c.pred * quant[c.tq][0];
+        c.pred += t ? extend(br.get(t), t) : 0;
+        blk[0] = (int16_t)c.pred;
         for (int k = 1; k < 64;) {
             int rs = decode_symbol(br, ha);
             int r = rs >> 4, s = rs & 15;
@@ -243,32 +255,127 @@ struct Decoder {
             }
             k += r;
             if (k > 63) bad("AC run overflows the block");
-            const int z = ZIGZAG[k];
-            coef[z] = extend(br.get(s), s) * quant[c.tq][z];
+            blk[ZIGZAG[k]] = (int16_t)extend(br.get(s), s);
             ++k;
         }
-        idct_islow(coef, c.plane.data() + ((size_t)by * 8 * c.blocks_w + (size_t)bx) * 8, c.blocks_w * 8);
+    }
+    // Progressive scans (T.81 G.1.2).  DC: the first scan carries the difference of the value's high bits, a later one ONE more bit.
+    void block_dc_first(BitReader &br, Component &c, int16_t *blk, int al) {
+        const HuffTable &hd = dc[c.td];
+        if (!hd.present) bad("missing table");
+        int t = decode_symbol(br, hd);
+        if (t > 11) bad("bad DC size");
+        c.pred += t ? extend(br.get(t), t) : 0;
+        blk[0] = (int16_t)(c.pred * (1 << al));
+    }
+    void block_dc_refine(BitReader &br, int16_t *blk, int al) {
+        if (br.get(1)) blk[0] = (int16_t)(blk[0] | (1 << al));
+    }
+    // AC, first pass over a band [ss, se]: as sequential, but an end-of-band code may cover a RUN of blocks (G.1.2.2)
+    void block_ac_first(BitReader &br, Component &c, int16_t *blk, int ss, int se, int al) {
+        if (eobrun > 0) { --eobrun; return; }
+        const HuffTable &ha = ac[c.ta];
+        if (!ha.present) bad("missing table");
+        for (int k = ss; k <= se;) {
+            int rs = decode_symbol(br, ha);
+            int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r < 15) { eobrun = (1u << r) - 1u; if (r) eobrun += (uint32_t)br.get(r); break; }
+                k += 16;
+                continue;
+            }
+            k += r;
+            if (k > se) bad("AC run overflows the band");
+            blk[ZIGZAG[k]] = (int16_t)(extend(br.get(s), s) * (1 << al));
+            ++k;
+        }
+    }
+    // AC, refinement (G.1.2.3): every coefficient that is already non-zero gets one correction bit as the scan passes it; a
+    // (run, 1) code places a NEW +-1 << al after `run` coefficients that are still zero
+    void block_ac_refine(BitReader &br, Component &c, int16_t *blk, int ss, int se, int al) {
+        const HuffTable &ha = ac[c.ta];
+        if (!ha.present) bad("missing table");
+        const int p1 = 1 << al, m1 = -(1 << al);
+        auto correct = [&](int16_t &v) {
+            if (br.get(1) && (v & p1) == 0) v = (int16_t)(v + (v >= 0 ? p1 : m1));
+        };
+        int k = ss;
+        if (eobrun == 0) {
+            for (; k <= se; ++k) {
+                int rs = decode_symbol(br, ha);
+                int r = rs >> 4, s = rs & 15, value = 0;
+                if (s) {
+                    if (s != 1) bad("bad refinement code");
+                    value = br.get(1) ? p1 : m1;
+                } else if (r != 15) {
+                    eobrun = 1u << r;
+                    if (r) eobrun += (uint32_t)br.get(r);
+                    break;
+                }
+                for (; k <= se; ++k) {
+                    int16_t &v = blk[ZIGZAG[k]];
+                    if (v != 0) correct(v);
+                    else if (--r < 0) break;
+                }
+                if (value) {
+                    if (k > se) bad("AC run overflows the band");
+                    blk[ZIGZAG[k]] = (int16_t)value;
+                }
+            }
+        }
+        if (eobrun > 0) {
+            for (; k <= se; ++k) {
+                int16_t &v = blk[ZIGZAG[k]];
+                if (v != 0) correct(v);
+            }
+            --eobrun;
+        }
     }
 
     void read_scan(int len) {
         (void)len;
         if (!have_frame) bad("SOS before SOF");
         int ns = u8();
-        if (ns != (int)comps.size()) bad("only single-scan (interleaved) files are supported");
+        if (ns < 1 || ns > (int)comps.size()) bad("bad component count in a scan");
+        std::vector<Component *> sc;
         for (int i = 0; i < ns; ++i) {
             int id = u8(), tdta = u8();
             Component *c = nullptr;
             for (auto &x : comps) if (x.id == id) c = &x;
             if (!c) bad("scan names an unknown component");
+            for (Component *o : sc) if (o == c) bad("scan names a component twice");
             c->td = tdta >> 4; c->ta = tdta & 15;
             if (c->td > 3 || c->ta > 3) bad("bad table selector");
+            if (!c->qt_latched) {
+                if (!quant_present[c->tq]) bad("missing table");
+                memcpy(c->qt, quant[c->tq], sizeof c->qt);
+                c->qt_latched = true;
+            }
+            sc.push_back(c);
         }
-        int ss = u8(), se = u8(), ahal = u8();
-        if (ss != 0 || se != 63 || ahal != 0) bad("progressive scans are not supported");
+        const int ss = u8(), se = u8(), ahal = u8();
+        const int ah = ahal >> 4, al = ahal & 15;
+        if (!progressive) {
+            if (ss != 0 || se != 63 || ahal != 0) bad("bad scan parameters for a sequential file");
+        } else {
+            if (ss > se || se > 63 || al > 13 || (ah != 0 && ah != al + 1)) bad("bad progressive scan parameters");
+            if (ss == 0 ? se != 0 : ns != 1) bad("bad progressive scan parameters"); // DC scans carry DC only; AC scans one component
+        }
         BitReader br{data + pos, data + size};
-        const int mcus_x = (width + 8 * max_h - 1) / (8 * max_h), mcus_y = (height + 8 * max_v - 1) / (8 * max_v);
+        eobrun = 0;
+        auto one_block = [&](Component &c, int bx, int by) {
+            int16_t *blk = block_of(c, bx, by);
+            if (!progressive) block_sequential(br, c, blk);
+            else if (ss == 0) { if (ah == 0) block_dc_first(br, c, blk, al); else block_dc_refine(br, blk, al); }
+            else if (ah == 0) block_ac_first(br, c, blk, ss, se, al);
+            else block_ac_refine(br, c, blk, ss, se, al);
+        };
+        // a scan of ONE component walks that component's own blocks, row by row, without the padding to whole MCUs (T.81 A.2.3)
+        const bool single = ns == 1;
+        const int mcus_x = single ? (sc[0]->width + 7) / 8 : (width + 8 * max_h - 1) / (8 * max_h);
+        const int mcus_y = single ? (sc[0]->height + 7) / 8 : (height + 8 * max_v - 1) / (8 * max_v);
         int until_restart = restart_interval;
-        for (auto &c : comps) c.pred = 0;
+        for (Component *c : sc) c->pred = 0;
         for (int my = 0; my < mcus_y; ++my)
             for (int mx = 0; mx < mcus_x; ++mx) {
                 if (restart_interval && until_restart == 0) {
@@ -276,17 +383,36 @@ struct Decoder {
                     const uint8_t *q = br.p;
                     while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
                     if (q + 1 >= br.end) bad("missing restart marker");
+                    if (br.overran()) bad("truncated entropy-coded segment");
                     br.p = q + 2;
                     br.reset();
-                    for (auto &c : comps) c.pred = 0;
+                    for (Component *c : sc) c->pred = 0;
+                    eobrun = 0;
                     until_restart = restart_interval;
                 }
-                for (auto &c : comps)
-                    for (int v = 0; v < c.v; ++v)
-                        for (int h = 0; h < c.h; ++h) decode_block(br, c, mx * c.h + h, my * c.v + v);
+                if (single) one_block(*sc[0], mx, my);
+                else
+                    for (Component *c : sc)
+                        for (int v = 0; v < c->v; ++v)
+                            for (int h = 0; h < c->h; ++h) one_block(*c, mx * c->h + h, my * c->v + v);
                 if (restart_interval) --until_restart;
             }
+        if (br.overran()) bad("truncated entropy-coded segment");
         pos = (size_t)(br.p - data);
+    }
+
+    // after the last scan: dequantise and transform every block
+    void reconstruct() {
+        for (auto &c : comps) {
+            if (!c.qt_latched) bad("a component has no scan");
+            for (int by = 0; by < c.blocks_h; ++by)
+                for (int bx = 0; bx < c.blocks_w; ++bx) {
+                    const int16_t *blk = block_of(c, bx, by);
+                    int32_t coef[64];
+                    for (int i = 0; i < 64; ++i) coef[i] = (int32_t)blk[i] * c.qt[i];
+                    idct_islow(coef, c.plane.data() + ((size_t)by * 8 * c.blocks_w + (size_t)bx) * 8, c.blocks_w * 8);
+                }
+        }
     }
 
     // IJG jdsample.c: h2v1 / h2v2 "fancy" (triangle filter) upsampling, plain replication otherwise
@@ -357,10 +483,12 @@ struct Decoder {
 
     ImageRGB8 run() {
         if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) bad("not a JPEG stream");
-        bool done = false;
-        while (!done) {
+        bool done = false; // (a scan has been read)
+        for (;;) {
+            if (pos >= size) { if (done) break; bad("truncated"); } // (files without an EOI marker exist: what was decoded stands)
             int b = u8();
             if (b != 0xFF) continue;
+            if (pos >= size) break;
             int m = u8();
             while (m == 0xFF) m = u8();
             if (m == 0x00 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
@@ -371,20 +499,24 @@ struct Decoder {
             switch (m) {
             case 0xDB: read_dqt(len); break;
             case 0xC4: read_dht(len); break;
-            case 0xC0: case 0xC1: read_sof(len); break;
-            case 0xC2: bad("progressive JPEG is not supported (baseline only)");
+            case 0xC0: case 0xC1: case 0xC2:
+                if (have_frame) bad("more than one frame");
+                progressive = m == 0xC2;
+                read_sof(len);
+                break;
             case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
                 bad("unsupported JPEG process");
             case 0xDD: restart_interval = u16(); break;
             case 0xEE: // Adobe: colour transform flag
                 if (len >= 12 && memcmp(data + pos, "Adobe", 5) == 0) adobe_transform = data[pos + 11];
                 break;
-            case 0xDA: read_scan(len); done = true; break;
+            case 0xDA: read_scan(len); done = true; break; // (pos now stands behind the scan's entropy-coded data)
             default: break;
             }
             if (m != 0xDA) pos = next;
         }
         if (!have_frame || !done) bad("no image data");
+        reconstruct();
 
         ImageRGB8 img;
         img.width = width; img.height = height;
@@ -422,7 +554,7 @@ struct Decoder {
 
 } // namespace
 
-ImageRGB8 decode_baseline_jpeg(const uint8_t *data, size_t size) {
+ImageRGB8 decode_jpeg(const uint8_t *data, size_t size) {
     if (!data) bad("null input");
     return Decoder(data, size).run();
 }

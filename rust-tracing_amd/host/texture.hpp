@@ -73,7 +73,7 @@ class CheckerTexture : public Texture {
 };
 
 // src/texture.rs:72-93.  The reference decodes with the `image` crate (src/texture.rs:78); here the decode
-// is image_io.hpp's (PPM/PNM and baseline JPEG, or a procedural stand-in "synthetic:WxH").
+// is image_io.hpp's (PPM, JPEG and PNG, or a procedural stand-in "synthetic:WxH").
 class ImageTexture : public Texture {
   public:
     explicit ImageTexture(const std::string &path) : image(load_image_rgb8(path)) {}

@@ -203,12 +203,28 @@ def test_jpeg_decoder_matches_pillow(rt, tmp_path):
         assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), got.ctypes.data_as(C.POINTER(C.c_uint8)), got.size) == 0
         assert (h.value, w.value) == want.shape[:2], name
         assert np.array_equal(got.reshape(want.shape), want), name
-    # progressive files are refused with a message, not mis-decoded
-    path = tmp_path / "prog.jpg"
-    Image.fromarray(img).save(path, "JPEG", progressive=True)
+    # progressive files (spectral selection + successive approximation, T.81 Annex G; Pillow writes libjpeg's standard ten-scan
+    # script): the same coefficients arrive in another order, so the decode must equal Pillow's here too
+    for name, src, kw in [("prog_420", img, dict(quality=85)), ("prog_444", img, dict(subsampling=0, quality=95)),
+                          ("prog_gray", img[:, :, 1], dict(quality=70)), ("prog_tiny", img[:9, :17], dict(quality=90)),
+                          ("prog_422_lowq", img, dict(subsampling=1, quality=15))]:
+        path = tmp_path / f"{name}.jpg"
+        Image.fromarray(src).save(path, "JPEG", progressive=True, **kw)
+        assert b"\xff\xc2" in path.read_bytes()           # really a progressive frame
+        want = np.asarray(Image.open(path).convert("RGB"))
+        w, h = C.c_int32(), C.c_int32()
+        assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0) == 0, lib.rth_last_error()
+        got = np.zeros(w.value * h.value * 3, dtype=np.uint8)
+        assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), got.ctypes.data_as(C.POINTER(C.c_uint8)), got.size) == 0
+        assert np.array_equal(got.reshape(want.shape), want), name
+    # a truncated progressive file is an error, not a crash; an arithmetic-coded frame is refused by name
+    data = (tmp_path / "prog_420.jpg").read_bytes()
+    (tmp_path / "cut.jpg").write_bytes(data[:len(data) // 20])
     w, h = C.c_int32(), C.c_int32()
-    assert lib.rth_load_image(str(path).encode(), C.byref(w), C.byref(h), None, 0) != 0
-    assert b"progressive" in lib.rth_last_error()
+    assert lib.rth_load_image(str(tmp_path / "cut.jpg").encode(), C.byref(w), C.byref(h), None, 0) != 0
+    (tmp_path / "arith.jpg").write_bytes(data.replace(b"\xff\xc2", b"\xff\xca", 1))
+    assert lib.rth_load_image(str(tmp_path / "arith.jpg").encode(), C.byref(w), C.byref(h), None, 0) != 0
+    assert b"unsupported JPEG process" in lib.rth_last_error()
     # and a texture built from a JPEG reaches the scene description
     Image.fromarray(img).save(tmp_path / "earth.jpg", "JPEG", quality=90)
     hs = rt.HostScene(2, spp=1, earth_image=str(tmp_path / "earth.jpg"))
