@@ -26,7 +26,7 @@ typedef struct rth_scene_options {
     double aspect_ratio;       /* <= 0: the scene's in-code value                                        */
     int32_t samples_per_pixel; /* <= 0: the scene's in-code value                                        */
     int32_t max_depth;         /* <= 0: the scene's in-code value                                        */
-    const char *earth_image;   /* NULL: "synthetic:1024x512"; else a path (PPM, JPEG, 8-bit PNG) or "synthetic:WxH"  */
+    const char *earth_image;   /* NULL: "synthetic:1024x512"; else a path (PPM, JPEG, PNG) or "synthetic:WxH"  */
 } rth_scene_options;
 
 /* Builds scene + top-level BVH + camera exactly as `main` does (src/main.rs:645-660) and describes them. */
@@ -42,7 +42,7 @@ int rth_resolve_rgb8(int32_t width, int32_t height, int32_t spp, const double *r
 int rth_write_png(const char *path, int32_t width, int32_t height, const uint8_t *rgb8);
 /* Deterministic procedural RGB8 map used where assets/earth-large.jpg is unavailable. */
 int rth_synthetic_earth(int32_t width, int32_t height, uint8_t *out_rgb8);
-/* Image ingest used by ImageTexture (PPM / JPEG, sequential or progressive / 8-bit PNG / synthetic:WxH); out_rgb8 may be NULL to query size. */
+/* Image ingest used by ImageTexture (PPM / JPEG, sequential or progressive / PNG / synthetic:WxH); out_rgb8 may be NULL to query size. */
 int rth_load_image(const char *path, int32_t *out_width, int32_t *out_height, uint8_t *out_rgb8, int64_t capacity);
 
 const char *rth_last_error(void);

@@ -106,9 +106,10 @@ static inline int paeth_predictor(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// PNG (ISO 15948), non-interlaced, 8 bits per channel: grey, grey + alpha, RGB, palette, RGBA.  The reference reads a texel with
-// DynamicImage::get_pixel (src/texture.rs:89), i.e. as RGBA8 whatever the file holds: grey is replicated, a palette looked up, alpha
-// dropped ([r, g, b, _]).  16-bit samples and Adam7 interlacing are refused with a message rather than guessed at.
+// PNG (ISO 15948): grey, grey + alpha, RGB, palette, RGBA at every bit depth the standard allows, plain or Adam7-interlaced.  The
+// reference reads a texel with DynamicImage::get_pixel (src/texture.rs:89), i.e. as RGBA8 whatever the file holds: grey is replicated
+// (1 / 2 / 4-bit grey scaled to 0..255), a palette looked up, alpha dropped ([r, g, b, _]), a 16-bit sample v becomes (v + 128) / 257 —
+// round(v * 255 / 65535), the `image` crate's u16 -> u8 conversion.
 static ImageRGB8 decode_png(const std::string &path, const std::vector<uint8_t> &file) {
     auto fail = [&](const char *what) -> ImageRGB8 { throw std::runtime_error("load_image_rgb8: " + path + ": PNG: " + what); };
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
@@ -139,57 +140,93 @@ static ImageRGB8 decode_png(const std::string &path, const std::vector<uint8_t> 
         at += 12u + (size_t)len;
     }
     if (colour < 0 || width == 0 || height == 0 || width > 65535u || height > 65535u) return fail("missing or bad IHDR");
-    if (interlace != 0) return fail("Adam7-interlaced files are not supported");
-    if (depth != 8) return fail("only 8 bits per sample are supported");
+    if (interlace != 0 && interlace != 1) return fail("unknown interlace method");
     int channels = 0;
+    bool depth_ok = false;
     switch (colour) {
-    case 0: channels = 1; break;
-    case 2: channels = 3; break;
-    case 3: channels = 1; if (palette.size() < 3 || palette.size() % 3 != 0) return fail("palette image without a PLTE chunk"); break;
-    case 4: channels = 2; break;
-    case 6: channels = 4; break;
+    case 0: channels = 1; depth_ok = depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16; break;
+    case 2: channels = 3; depth_ok = depth == 8 || depth == 16; break;
+    case 3:
+        channels = 1; depth_ok = depth == 1 || depth == 2 || depth == 4 || depth == 8;
+        if (palette.size() < 3 || palette.size() % 3 != 0) return fail("palette image without a PLTE chunk");
+        break;
+    case 4: channels = 2; depth_ok = depth == 8 || depth == 16; break;
+    case 6: channels = 4; depth_ok = depth == 8 || depth == 16; break;
     default: return fail("unknown colour type");
     }
-    const size_t stride = (size_t)width * (size_t)channels;
-    std::vector<uint8_t> raw((stride + 1u) * (size_t)height);
+    if (!depth_ok) return fail("bit depth not allowed for the colour type");
+    const size_t bits_pp = (size_t)channels * (size_t)depth;  // bits per pixel
+    const size_t fbpp = bits_pp >= 8 ? bits_pp / 8 : 1;        // the filters' "corresponding byte of the pixel to the left"
+    // the image as a sequence of reduced images (ISO 15948 section 8.2): one for a plain file, seven for Adam7
+    struct Pass { uint32_t x0, y0, dx, dy, w, h; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back({0, 0, 1, 1, width, height});
+    else {
+        static const uint32_t A7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+        for (const auto &a : A7) {
+            const uint32_t pw = width > a[0] ? (width - a[0] + a[2] - 1) / a[2] : 0, ph = height > a[1] ? (height - a[1] + a[3] - 1) / a[3] : 0;
+            if (pw && ph) passes.push_back({a[0], a[1], a[2], a[3], pw, ph});
+        }
+    }
+    size_t total = 0;
+    for (const Pass &ps : passes) total += (((size_t)ps.w * bits_pp + 7) / 8 + 1u) * (size_t)ps.h;
+    std::vector<uint8_t> raw(total);
     uLongf raw_len = (uLongf)raw.size();
     const int zrc = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if (zrc != Z_OK || raw_len != raw.size()) return fail("image data does not inflate to the size IHDR announces");
-    // undo the per-row filters in place (ISO 15948 section 9)
-    std::vector<uint8_t> zero(stride, 0);
-    for (uint32_t y = 0; y < height; ++y) {
-        uint8_t *row = raw.data() + (size_t)y * (stride + 1u);
-        const int filter = row[0];
-        uint8_t *cur = row + 1;
-        const uint8_t *up = y ? row - stride : zero.data();
-        if (filter < 0 || filter > 4) return fail("unknown row filter");
-        for (size_t x = 0; x < stride; ++x) {
-            const int a = x >= (size_t)channels ? cur[x - (size_t)channels] : 0, b = up[x], c = x >= (size_t)channels ? up[x - (size_t)channels] : 0;
-            int v = cur[x];
-            switch (filter) {
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth_predictor(a, b, c); break;
-            default: break;
-            }
-            cur[x] = (uint8_t)v;
-        }
-    }
     auto px = std::make_shared<std::vector<uint8_t>>((size_t)width * (size_t)height * 3u);
-    for (uint32_t y = 0; y < height; ++y) {
-        const uint8_t *cur = raw.data() + (size_t)y * (stride + 1u) + 1u;
-        uint8_t *dst = px->data() + (size_t)y * (size_t)width * 3u;
-        for (uint32_t x = 0; x < width; ++x) {
-            const uint8_t *sp = cur + (size_t)x * (size_t)channels;
-            uint8_t r, g, b;
-            if (colour == 0 || colour == 4) { r = g = b = sp[0]; }
-            else if (colour == 3) {
-                if ((size_t)sp[0] * 3u + 2u >= palette.size()) return fail("palette index out of range");
-                r = palette[(size_t)sp[0] * 3u]; g = palette[(size_t)sp[0] * 3u + 1u]; b = palette[(size_t)sp[0] * 3u + 2u];
-            } else { r = sp[0]; g = sp[1]; b = sp[2]; }
-            dst[x * 3u] = r; dst[x * 3u + 1u] = g; dst[x * 3u + 2u] = b;
+    auto to8 = [&](uint32_t v) -> uint8_t { // a sample of `depth` bits as the `image` crate hands it out in 8
+        switch (depth) {
+        case 1: return (uint8_t)(v * 255u);
+        case 2: return (uint8_t)(v * 85u);
+        case 4: return (uint8_t)(v * 17u);
+        case 8: return (uint8_t)v;
+        default: return (uint8_t)((v + 128u) / 257u);
         }
+    };
+    size_t at_raw = 0;
+    for (const Pass &ps : passes) {
+        const size_t stride = ((size_t)ps.w * bits_pp + 7) / 8;
+        const std::vector<uint8_t> zero(stride, 0);
+        for (uint32_t y = 0; y < ps.h; ++y) {
+            // undo the row's filter in place (ISO 15948 section 9)
+            uint8_t *row = raw.data() + at_raw + (size_t)y * (stride + 1u);
+            const int filter = row[0];
+            uint8_t *cur = row + 1;
+            const uint8_t *up = y ? row - stride : zero.data();
+            if (filter < 0 || filter > 4) return fail("unknown row filter");
+            for (size_t x = 0; x < stride; ++x) {
+                const int a = x >= fbpp ? cur[x - fbpp] : 0, b = up[x], c = x >= fbpp ? up[x - fbpp] : 0;
+                int v = cur[x];
+                switch (filter) {
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth_predictor(a, b, c); break;
+                default: break;
+                }
+                cur[x] = (uint8_t)v;
+            }
+            auto sample = [&](uint32_t i, int ch) -> uint32_t { // channel ch of the row's pixel i, as stored
+                if (depth == 8) return cur[(size_t)i * (size_t)channels + (size_t)ch];
+                if (depth == 16) { const uint8_t *q = cur + ((size_t)i * (size_t)channels + (size_t)ch) * 2u; return ((uint32_t)q[0] << 8) | q[1]; }
+                const size_t bit = (size_t)i * (size_t)depth; // (one channel below 8 bits) samples are packed from the high bit down
+                return (cur[bit >> 3] >> (8u - (unsigned)depth - (bit & 7u))) & ((1u << depth) - 1u);
+            };
+            uint8_t *dst_row = px->data() + (size_t)(ps.y0 + y * ps.dy) * (size_t)width * 3u;
+            for (uint32_t i = 0; i < ps.w; ++i) {
+                uint8_t r, g, b;
+                if (colour == 0 || colour == 4) { r = g = b = to8(sample(i, 0)); }
+                else if (colour == 3) {
+                    const size_t idx = sample(i, 0);
+                    if (idx * 3u + 2u >= palette.size()) return fail("palette index out of range");
+                    r = palette[idx * 3u]; g = palette[idx * 3u + 1u]; b = palette[idx * 3u + 2u];
+                } else { r = to8(sample(i, 0)); g = to8(sample(i, 1)); b = to8(sample(i, 2)); }
+                uint8_t *dst = dst_row + (size_t)(ps.x0 + i * ps.dx) * 3u;
+                dst[0] = r; dst[1] = g; dst[2] = b;
+            }
+        }
+        at_raw += (stride + 1u) * (size_t)ps.h;
     }
     ImageRGB8 img;
     img.width = (int32_t)width; img.height = (int32_t)height; img.pixels = px;
@@ -222,7 +259,7 @@ ImageRGB8 load_image_rgb8(const std::string &path) {
                 throw std::runtime_error("load_image_rgb8: short read on " + path);
             img = head[0] == 0xFF ? decode_jpeg(bytes.data(), bytes.size()) : decode_png(path, bytes);
         } else {
-            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6, JPEG or 8-bit PNG)");
+            throw std::runtime_error("load_image_rgb8: " + path + ": unsupported format (PPM P6, JPEG or PNG)");
         }
         fclose(f);
         return img;

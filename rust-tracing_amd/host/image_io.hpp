@@ -15,7 +15,7 @@ struct ImageRGB8 {
 
 // Accepts: "synthetic:WxH" (deterministic integer-only procedural earth-like map, used where the reference's
 // assets/earth-large.jpg is not available), binary PPM (P6, maxval 255), JPEG (sequential or progressive, 8-bit) and
-// 8-bit non-interlaced PNG.
+// PNG (every bit depth, plain or Adam7-interlaced).
 // Throws std::runtime_error on failure (the reference panics: `.unwrap()`, src/texture.rs:78).
 ImageRGB8 load_image_rgb8(const std::string &path);
 

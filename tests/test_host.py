@@ -234,7 +234,8 @@ def test_jpeg_decoder_matches_pillow(rt, tmp_path):
 def test_png_reader_matches_pillow(rt, tmp_path):
     """ImageTexture ingest of PNG files (the reference opens any format the `image` crate knows, src/texture.rs:78, and reads texels as
     RGBA8 through get_pixel: grey replicated, palettes looked up, alpha dropped): grey, grey + alpha, RGB, RGBA and palette images come
-    out as Pillow's convert("RGB") has them; the library's own PNG writer round-trips; what is not supported is refused by name."""
+    out as Pillow's convert("RGB") has them; so does every bit depth, plain or Adam7-interlaced; the library's own PNG writer round-trips;
+    malformed files are refused by name."""
     from PIL import Image
     lib = rt.host_lib()
     rng = np.random.default_rng(5)
@@ -260,11 +261,87 @@ def test_png_reader_matches_pillow(rt, tmp_path):
     own = tmp_path / "own.png"
     assert lib.rth_write_png(str(own).encode(), W, H, np.ascontiguousarray(rgb).ctypes.data_as(C.POINTER(C.c_uint8))) == 0
     assert np.array_equal(load(own), rgb) and np.array_equal(np.asarray(Image.open(own).convert("RGB")), rgb)
-    # refused, with the reason: 16 bits per sample, interlacing, a damaged file
-    Image.fromarray((rgb[:, :, 0].astype(np.uint16) << 8)).save(tmp_path / "deep.png")
-    Image.fromarray(rgb).save(tmp_path / "adam7.png", "PNG", interlace=True) if hasattr(Image, "ADAPTIVE") else None
+    # every other form the standard allows — 1 / 2 / 4-bit grey and palette, 16-bit samples, Adam7 interlacing, all five row filters —
+    # written by a small PNG writer of the test's own, so that the expected texels follow from the source arrays: low-depth grey scaled
+    # to 0..255, a 16-bit sample v as (v + 128) // 257 (the `image` crate's u16 -> u8)
+    import struct, zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+    def paeth(a, b, c):
+        pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def pack_rows(samples, depth):  # samples: (h, w, channels) integers -> one bytes object per row
+        rows = []
+        for line in samples.reshape(samples.shape[0], -1):
+            if depth == 16:
+                rows.append(b"".join(struct.pack(">H", int(v)) for v in line))
+            elif depth == 8:
+                rows.append(bytes(int(v) for v in line))
+            else:
+                bits = "".join(format(int(v), f"0{depth}b") for v in line)
+                bits += "0" * (-len(bits) % 8)
+                rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+        return rows
+
+    def filtered(rows, fbpp, first_filter):
+        out, prev = b"", bytes(len(rows[0])) if rows else b""
+        for y, cur in enumerate(rows):
+            f = (first_filter + y) % 5
+            line = bytearray()
+            for x, v in enumerate(cur):
+                a = cur[x - fbpp] if x >= fbpp else 0
+                c = prev[x - fbpp] if x >= fbpp else 0
+                pred = (0, a, prev[x], (a + prev[x]) >> 1, paeth(a, prev[x], c))[f]
+                line.append((v - pred) & 255)
+            out += bytes([f]) + bytes(line)
+            prev = cur
+        return out
+
+    def make_png(samples, depth, colour, interlace, palette=None):
+        h, w, ch = samples.shape
+        fbpp = max(1, ch * depth // 8)
+        body = b""
+        if interlace:
+            for k, (x0, y0, dx, dy) in enumerate([(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]):
+                sub = samples[y0::dy, x0::dx]
+                if sub.size:
+                    body += filtered(pack_rows(sub, depth), fbpp, k)
+        else:
+            body = filtered(pack_rows(samples, depth), fbpp, 1)
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 1 if interlace else 0))
+        if palette is not None:
+            png += chunk(b"PLTE", bytes(int(v) for v in palette.reshape(-1)))
+        half = len(zlib.compress(body)) // 2
+        z = zlib.compress(body)
+        return png + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+    H2, W2 = 19, 21  # (not a multiple of 8: the Adam7 passes are ragged, two of them one column wide at the edge)
+    for depth, colour, ch in [(1, 0, 1), (2, 0, 1), (4, 0, 1), (16, 0, 1), (16, 2, 3), (16, 4, 2), (16, 6, 4), (8, 2, 3), (8, 6, 4),
+                              (1, 3, 1), (2, 3, 1), (4, 3, 1), (8, 3, 1)]:
+        for interlace in (False, True):
+            smp = rng.integers(0, 1 << depth, (H2, W2, ch))
+            pal = rng.integers(0, 256, (1 << depth, 3)) if colour == 3 else None
+            path = tmp_path / f"d{depth}_c{colour}_{int(interlace)}.png"
+            path.write_bytes(make_png(smp, depth, colour, interlace, pal))
+            if colour == 3:
+                want = pal[smp[:, :, 0]]
+            else:
+                to8 = {1: lambda v: v * 255, 2: lambda v: v * 85, 4: lambda v: v * 17, 8: lambda v: v, 16: lambda v: (v + 128) // 257}[depth]
+                want = to8(smp[:, :, :3]) if ch >= 3 else np.repeat(to8(smp[:, :, :1]), 3, axis=2)
+            assert np.array_equal(load(path), want.astype(np.uint8)), path.name
+            if depth <= 8:  # (the test's writer itself, against Pillow)
+                assert np.array_equal(np.asarray(Image.open(path).convert("RGB")), want.astype(np.uint8)), path.name
+    # a one-pixel interlaced image has six empty passes
+    path = tmp_path / "one.png"
+    path.write_bytes(make_png(np.array([[[7, 200, 31]]]), 8, 2, True))
+    assert load(path).tolist() == [[[7, 200, 31]]]
+    # refused, with the reason: a depth the colour type does not have, a damaged file
     w, h = C.c_int32(), C.c_int32()
-    assert lib.rth_load_image(str(tmp_path / "deep.png").encode(), C.byref(w), C.byref(h), None, 0) != 0 and b"8 bits" in lib.rth_last_error()
+    (tmp_path / "bad_depth.png").write_bytes(make_png(rng.integers(0, 16, (4, 4, 3)), 4, 2, False))
+    assert lib.rth_load_image(str(tmp_path / "bad_depth.png").encode(), C.byref(w), C.byref(h), None, 0) != 0 and b"bit depth" in lib.rth_last_error()
     damaged = bytearray((tmp_path / "rgb.png").read_bytes()); damaged[60] ^= 0x40
     (tmp_path / "damaged.png").write_bytes(bytes(damaged))
     assert lib.rth_load_image(str(tmp_path / "damaged.png").encode(), C.byref(w), C.byref(h), None, 0) != 0 and b"PNG" in lib.rth_last_error()
