@@ -625,11 +625,13 @@ int rt_scene_create_ex(const rt_scene_desc *desc, int device, const rt_scene_opt
     if (cs.ordered)
         for (Instance &in : cs.instances) {
             uint32_t only = 0, n = 0;
-            auto look = [&](uint32_t ref) { if ((ref >> OREF_KIND_SHIFT) != OK_EMPTY) { ++n; only = ref; } };
-            if (s->wide) for (int k = 0; k < 4; ++k) look(cs.onodes4[in.root].c[k]);
-            else for (int k = 0; k < 2; ++k) look(cs.onodes[in.root].c[k]);
+            const float *box = nullptr;
+            auto look = [&](uint32_t ref, const float *b) { if ((ref >> OREF_KIND_SHIFT) != OK_EMPTY) { ++n; only = ref; box = b; } };
+            if (s->wide) for (int k = 0; k < 4; ++k) look(cs.onodes4[in.root].c[k], cs.onodes4[in.root].b[k]);
+            else { look(cs.onodes[in.root].c[0], cs.onodes[in.root].b0); look(cs.onodes[in.root].c[1], cs.onodes[in.root].b1); }
             const uint32_t kind = only >> OREF_KIND_SHIFT;
             in.start_ref = (n == 1 && (kind == OK_SPHERES || kind == OK_QUADS)) ? only : 0u;
+            if (in.start_ref) memcpy(in.start_box, box, sizeof in.start_box);
         }
     for (const ONode &nd : cs.onodes)
         for (int k = 0; k < 6; ++k) {

@@ -774,7 +774,17 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const uint32_t start = (LDS == 3 && !HAS_MEDIA && !leaving && P.inst_shortcut != 0u) ? inst_tab[cur_inst].start_ref : 0u;
                     if (start == 0u) refresh_ray32();
                     a = len2(d);
-                    if (leaving) o_next(false, 0u);
+                    // (... but the box that was tested there is the frame's box in the PARENT's coordinates — around a rotated box it is a
+                    // fifth wider than the box —, and against the interval of that moment: the leaf's own box, in the frame's coordinates,
+                    // is tested here, and a ray that misses it goes on as if the leaf had been looked at)
+                    bool nothing = false;
+                    if (start != 0u) {
+                        const float *sb = inst_tab[cur_inst].start_box;
+                        const float lo[3] = {sb[0], sb[2], sb[4]}, hi[3] = {sb[1], sb[3], sb[5]};
+                        nothing = box_miss_f32(lo, hi, make_ray32(o, d), tmin32, tmax32);
+                        if (COUNT && nothing) cn.instance_enters--; // (the counter: frames entered AND looked at)
+                    }
+                    if (leaving || nothing) o_next(false, 0u);
                     else {
                         node = inst_tab[cur_inst].root | W_FULL;
                         stage = ST_BOX;

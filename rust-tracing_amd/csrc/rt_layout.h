@@ -148,8 +148,11 @@ struct alignas(64) Instance {
     uint32_t start_ref; // ordered layout: != 0: that root holds nothing but ONE leaf (a box's six faces): its reference — a walk that enters
                         // the frame starts in the leaf's primitive stage, not with a visit of a record that has one thing to say
     uint32_t _pad;
+    float start_box[6]; // ... and that leaf's box in the frame's own coordinates (x.lo, x.hi, y.lo, y.hi, z.lo, z.hi; f32, rounded outward): the
+                        // walk met the instance through its box in the PARENT's frame — for a rotated box a fifth wider than the box itself
+    uint32_t _pad2[10];
 };
-static_assert(sizeof(Instance) == 64, "Instance must be 64 bytes");
+static_assert(sizeof(Instance) == 128, "Instance must be 128 bytes");
 constexpr uint32_t INST_TRANSLATE = 1u, INST_ROTATE = 2u;
 
 struct alignas(16) Medium {
