@@ -93,6 +93,7 @@ static ImageRGB8 load_ppm(const std::string &path, FILE *f) {
     skip(); if (fscanf(f, "%d", &maxv) != 1) throw std::runtime_error("load_image_rgb8: bad PPM header");
     fgetc(f); // single whitespace after maxval
     if (w <= 0 || h <= 0 || maxv != 255) throw std::runtime_error("load_image_rgb8: unsupported PPM");
+    if ((uint64_t)w * (uint64_t)h > MAX_IMAGE_PIXELS) throw std::runtime_error("load_image_rgb8: " + path + ": image too large");
     auto px = std::make_shared<std::vector<uint8_t>>((size_t)w * (size_t)h * 3u);
     if (fread(px->data(), 1, px->size(), f) != px->size())
         throw std::runtime_error("load_image_rgb8: " + path + ": truncated PPM");
@@ -140,6 +141,7 @@ static ImageRGB8 decode_png(const std::string &path, const std::vector<uint8_t> 
         at += 12u + (size_t)len;
     }
     if (colour < 0 || width == 0 || height == 0 || width > 65535u || height > 65535u) return fail("missing or bad IHDR");
+    if ((uint64_t)width * (uint64_t)height > MAX_IMAGE_PIXELS) return fail("image too large");
     if (interlace != 0 && interlace != 1) return fail("unknown interlace method");
     int channels = 0;
     bool depth_ok = false;

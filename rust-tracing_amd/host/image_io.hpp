@@ -8,6 +8,9 @@
 
 namespace rt {
 
+// The readers refuse a file that announces more pixels than this before allocating anything for it (2^28: a 16 384 x 16 384 texture)
+constexpr uint64_t MAX_IMAGE_PIXELS = 1ull << 28;
+
 struct ImageRGB8 {
     int32_t width = 0, height = 0;
     std::shared_ptr<const std::vector<uint8_t>> pixels; // row-major RGB8, row 0 = top

@@ -37,6 +37,7 @@ struct HuffTable {
         for (int len = 1; len <= 16; ++len) {
             valptr[len] = k;
             mincode[len] = code;
+            if (code + counts[len - 1] > (1 << len)) bad("over-subscribed Huffman table"); // (more codes of this length than there are)
             for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
                 if (len <= 9) {
                     const int shift = 9 - len;
@@ -115,46 +116,49 @@ constexpr int CONST_BITS = 13, PASS1_BITS = 2;
 constexpr int32_t FIX_0_298631336 = 2446, FIX_0_390180644 = 3196, FIX_0_541196100 = 4433, FIX_0_765366865 = 6270,
                   FIX_0_899976223 = 7373, FIX_1_175875602 = 9633, FIX_1_501321110 = 12299, FIX_1_847759065 = 15137,
                   FIX_1_961570560 = 16069, FIX_2_053119869 = 16819, FIX_2_562915447 = 20995, FIX_3_072711026 = 25172;
-inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
-inline uint8_t clamp255(int32_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// (64-bit intermediates: a valid file never leaves the 32-bit range IJG computes in — the results are IJG's —, a damaged one, whose
+// coefficients can be anything, must not overflow a signed integer either)
+using wide_t = int64_t;
+inline wide_t descale(wide_t x, int n) { return (x + ((wide_t)1 << (n - 1))) >> n; }
+inline uint8_t clamp255(wide_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
 void idct_islow(const int32_t coef[64], uint8_t *out, int stride) {
-    int32_t ws[64];
+    wide_t ws[64];
     for (int c = 0; c < 8; ++c) { // pass 1: columns
         const int32_t *in = coef + c;
-        int32_t z2 = in[16], z3 = in[48];
-        int32_t z1 = (z2 + z3) * FIX_0_541196100;
-        int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
-        int32_t tmp3 = z1 + z2 * FIX_0_765366865;
+        wide_t z2 = in[16], z3 = in[48];
+        wide_t z1 = (z2 + z3) * FIX_0_541196100;
+        wide_t tmp2 = z1 + z3 * (-FIX_1_847759065);
+        wide_t tmp3 = z1 + z2 * FIX_0_765366865;
         z2 = in[0]; z3 = in[32];
-        int32_t tmp0 = (z2 + z3) * (1 << CONST_BITS), tmp1 = (z2 - z3) * (1 << CONST_BITS);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        wide_t tmp0 = (z2 + z3) * ((wide_t)1 << CONST_BITS), tmp1 = (z2 - z3) * ((wide_t)1 << CONST_BITS);
+        const wide_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * FIX_1_175875602;
+        wide_t z4 = tmp1 + tmp3;
+        const wide_t z5 = (z3 + z4) * FIX_1_175875602;
         tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
         z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        int32_t *w = ws + c;
+        wide_t *w = ws + c;
         w[0] = descale(tmp10 + tmp3, CONST_BITS - PASS1_BITS);  w[56] = descale(tmp10 - tmp3, CONST_BITS - PASS1_BITS);
         w[8] = descale(tmp11 + tmp2, CONST_BITS - PASS1_BITS);  w[48] = descale(tmp11 - tmp2, CONST_BITS - PASS1_BITS);
         w[16] = descale(tmp12 + tmp1, CONST_BITS - PASS1_BITS); w[40] = descale(tmp12 - tmp1, CONST_BITS - PASS1_BITS);
         w[24] = descale(tmp13 + tmp0, CONST_BITS - PASS1_BITS); w[32] = descale(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
     }
     for (int r = 0; r < 8; ++r) { // pass 2: rows
-        const int32_t *w = ws + r * 8;
-        int32_t z2 = w[2], z3 = w[6];
-        int32_t z1 = (z2 + z3) * FIX_0_541196100;
-        int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
-        int32_t tmp3 = z1 + z2 * FIX_0_765366865;
-        int32_t tmp0 = (w[0] + w[4]) * (1 << CONST_BITS), tmp1 = (w[0] - w[4]) * (1 << CONST_BITS);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        const wide_t *w = ws + r * 8;
+        wide_t z2 = w[2], z3 = w[6];
+        wide_t z1 = (z2 + z3) * FIX_0_541196100;
+        wide_t tmp2 = z1 + z3 * (-FIX_1_847759065);
+        wide_t tmp3 = z1 + z2 * FIX_0_765366865;
+        wide_t tmp0 = (w[0] + w[4]) * ((wide_t)1 << CONST_BITS), tmp1 = (w[0] - w[4]) * ((wide_t)1 << CONST_BITS);
+        const wide_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * FIX_1_175875602;
+        wide_t z4 = tmp1 + tmp3;
+        const wide_t z5 = (z3 + z4) * FIX_1_175875602;
         tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
         z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
         z3 += z5; z4 += z5;
@@ -215,6 +219,7 @@ struct Decoder {
         height = u16(); width = u16();
         int nc = u8();
         if (width <= 0 || height <= 0) bad("empty image");
+        if ((uint64_t)width * (uint64_t)height > MAX_IMAGE_PIXELS) bad("image too large"); // (before anything is allocated for it)
         if (nc != 1 && nc != 3) bad("only grayscale and 3-component images are supported");
         comps.resize((size_t)nc);
         for (auto &c : comps) {
@@ -244,7 +249,7 @@ struct Decoder {
         if (!hd.present || !ha.present) bad("missing table");
         int t = decode_symbol(br, hd);
         if (t > 11) bad("bad DC size");
-        c.pred += t ? extend(br.get(t), t) : 0;
+        c.pred = (int16_t)(c.pred + (t ? extend(br.get(t), t) : 0)); // (a DC value has 16 bits at most: a damaged stream wraps, it does not overflow)
         blk[0] = (int16_t)c.pred;
         for (int k = 1; k < 64;) {
             int rs = decode_symbol(br, ha);
@@ -265,7 +270,7 @@ struct Decoder {
         if (!hd.present) bad("missing table");
         int t = decode_symbol(br, hd);
         if (t > 11) bad("bad DC size");
-        c.pred += t ? extend(br.get(t), t) : 0;
+        c.pred = (int16_t)(c.pred + (t ? extend(br.get(t), t) : 0)); // (a DC value has 16 bits at most: a damaged stream wraps, it does not overflow)
         blk[0] = (int16_t)(c.pred * (1 << al));
     }
     void block_dc_refine(BitReader &br, int16_t *blk, int al) {

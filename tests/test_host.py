@@ -222,6 +222,10 @@ def test_jpeg_decoder_matches_pillow(rt, tmp_path):
     (tmp_path / "cut.jpg").write_bytes(data[:len(data) // 20])
     w, h = C.c_int32(), C.c_int32()
     assert lib.rth_load_image(str(tmp_path / "cut.jpg").encode(), C.byref(w), C.byref(h), None, 0) != 0
+    at = data.index(b"\xff\xc4")                      # the first Huffman table: claim 255 codes of length one
+    (tmp_path / "huff.jpg").write_bytes(data[:at + 5] + b"\xff" + data[at + 6:])
+    assert lib.rth_load_image(str(tmp_path / "huff.jpg").encode(), C.byref(w), C.byref(h), None, 0) != 0
+    assert b"Huffman" in lib.rth_last_error()
     (tmp_path / "arith.jpg").write_bytes(data.replace(b"\xff\xc2", b"\xff\xca", 1))
     assert lib.rth_load_image(str(tmp_path / "arith.jpg").encode(), C.byref(w), C.byref(h), None, 0) != 0
     assert b"unsupported JPEG process" in lib.rth_last_error()
@@ -338,6 +342,11 @@ def test_png_reader_matches_pillow(rt, tmp_path):
     path = tmp_path / "one.png"
     path.write_bytes(make_png(np.array([[[7, 200, 31]]]), 8, 2, True))
     assert load(path).tolist() == [[[7, 200, 31]]]
+    # a header that announces an absurd size is refused before anything is allocated for it
+    (tmp_path / "huge.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 8, 2, 0, 0, 0))
+                                        + chunk(b"IDAT", zlib.compress(b"\0")) + chunk(b"IEND", b""))
+    w, h = C.c_int32(), C.c_int32()
+    assert lib.rth_load_image(str(tmp_path / "huge.png").encode(), C.byref(w), C.byref(h), None, 0) != 0 and b"too large" in lib.rth_last_error()
     # refused, with the reason: a depth the colour type does not have, a damaged file
     w, h = C.c_int32(), C.c_int32()
     (tmp_path / "bad_depth.png").write_bytes(make_png(rng.integers(0, 16, (4, 4, 3)), 4, 2, False))
