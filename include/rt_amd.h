@@ -288,7 +288,9 @@ typedef struct rt_scene_options {
                                     more (DESIGN.md "Wide records") */
     int32_t quad_filter;         /* -1 default (on); 0: every quad of a multi-quad leaf gets the exact test at once, without the conservative
                                     f32 filter in front of it (DESIGN.md "Quad filter") */
-    int32_t reserved_tail;       /* ignored */
+    int32_t medium_first;        /* -1 default (on); 0: off.  Own trees, scenes with media: a ray that starts inside the ball of a sphere-bounded
+                                    medium makes that medium's draw before the tree in front of it is walked, and walks the tree no further
+                                    than the draw's candidate (same results) */
 } rt_scene_options;
 /* Fills the defaults.  rt_scene_options_init writes sizeof(rt_scene_options) of THIS header: caller and library must have been built
  * from the same header.  A caller that may meet a newer library calls rt_scene_options_init_sized(&o, sizeof o) instead: only

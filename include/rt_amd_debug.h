@@ -20,7 +20,8 @@ typedef enum rt_debug_op {
     RT_DEBUG_LOG = 1, RT_DEBUG_SIN = 2, RT_DEBUG_ACOS = 3, RT_DEBUG_ATAN2 = 4 /* atan2(a, b) */, RT_DEBUG_POW5 = 5,
     RT_DEBUG_SQRT = 6, RT_DEBUG_DIV = 7 /* a / b */, RT_DEBUG_MUL_ADD = 8 /* a * b + a, two roundings */,
     RT_DEBUG_RNG_RANDOM = 9, RT_DEBUG_RNG_RANGE = 10 /* gen_range(-1.0..1.0) */,
-    RT_DEBUG_F32_ABOVE = 11, RT_DEBUG_F32_BELOW = 12 /* the ordered walk's outward f32 conversions of an interval end (as doubles) */
+    RT_DEBUG_F32_ABOVE = 11, RT_DEBUG_F32_BELOW = 12 /* the ordered walk's outward f32 conversions of an interval end (as doubles) */,
+    RT_DEBUG_RNG_UNNEXT = 13 /* random() number `b` of stream `a` after two draws too many were made and taken back (Rng::unnext) */
 } rt_debug_op;
 int rt_debug_eval(int32_t op, int64_t n, const double *a, const double *b, double *out, int device);
 

@@ -172,12 +172,12 @@ class SceneCreateOptions(C.Structure):
                 ("th_box", C.c_int32), ("th_new", C.c_int32), ("sample_buffer_bytes", C.c_int64), ("reserved_pool", C.c_int32),
                 ("flat_max", C.c_int32), ("start_shortcut", C.c_int32), ("defer_instances", C.c_int32),
                 ("seq_lookahead", C.c_int32), ("slow_min", C.c_int32), ("slow_age", C.c_int32), ("wide", C.c_int32),
-                ("quad_filter", C.c_int32), ("reserved_tail", C.c_int32)]
+                ("quad_filter", C.c_int32), ("medium_first", C.c_int32)]
 
 
 def scene_options(**kw) -> "SceneCreateOptions":
     """rt_scene_options_init, then the given fields (walk=, leaf_max=, flat_max=, refit=, use_lds=, th_*=, sample_buffer_bytes=,
-    start_shortcut=, defer_instances=, seq_lookahead=, slow_min=, slow_age=)."""
+    start_shortcut=, defer_instances=, seq_lookahead=, slow_min=, slow_age=, quad_filter=, medium_first=)."""
     o = SceneCreateOptions()
     amd_lib().rt_scene_options_init(C.byref(o))
     for k, v in kw.items():
@@ -251,7 +251,7 @@ RT_AMD_DEBUG_SYMBOLS = {
 }
 
 RT_DEBUG_LOG, RT_DEBUG_SIN, RT_DEBUG_ACOS, RT_DEBUG_ATAN2, RT_DEBUG_POW5, RT_DEBUG_SQRT, RT_DEBUG_DIV, \
-    RT_DEBUG_MUL_ADD, RT_DEBUG_RNG_RANDOM, RT_DEBUG_RNG_RANGE, RT_DEBUG_F32_ABOVE, RT_DEBUG_F32_BELOW = range(1, 13)
+    RT_DEBUG_MUL_ADD, RT_DEBUG_RNG_RANDOM, RT_DEBUG_RNG_RANGE, RT_DEBUG_F32_ABOVE, RT_DEBUG_F32_BELOW, RT_DEBUG_RNG_UNNEXT = range(1, 14)
 
 
 def debug_box_tests(rays, boxes, tmin, tmax, device=0):

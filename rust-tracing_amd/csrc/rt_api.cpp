@@ -26,7 +26,7 @@ Tuning::Tuning() {
     auto env = [](const char *name, int &v) { if (const char *e = getenv(name)) v = atoi(e); };
     env("RT_TH_PRIM", forced[0]); env("RT_TH_OTHER", forced[1]); env("RT_TH_SHADE", forced[2]); env("RT_TH_BOX", forced[3]); env("RT_TH_NEW", forced[4]);
     env("RT_USE_LDS", use_lds); env("RT_REFIT", refit); env("RT_ORDERED", ordered); env("RT_JOBS_PER_GRAB", jobs_per_grab); env("RT_GRAB_TAPER", grab_taper); env("RT_DEFER", defer); env("RT_START_SHORTCUT", start_shortcut); env("RT_SEQ_LOOKAHEAD", seq_lookahead); env("RT_SLOW_MIN", slow_min); env("RT_SLOW_AGE", slow_age); env("RT_OVERLAP", overlap);
-    env("RT_WIDE", wide); env("RT_QUAD_FILTER", quad_filter);
+    env("RT_WIDE", wide); env("RT_QUAD_FILTER", quad_filter); env("RT_MEDIUM_FIRST", medium_first);
     if (const char *e = getenv("RT_SAH_LEAF")) ordered_options.leaf_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_FLAT_MAX")) ordered_options.flat_max = (uint32_t)atoi(e);
     if (const char *e = getenv("RT_SAH_SPHERE")) ordered_options.cost_sphere = atof(e);
@@ -176,6 +176,7 @@ Tuning effective_tuning(const rt_scene *scene) {
     if (o.slow_min >= 1) tn.slow_min = o.slow_min;
     if (o.slow_age >= 0) tn.slow_age = o.slow_age;
     if (o.quad_filter >= 0) tn.quad_filter = o.quad_filter;
+    if (o.medium_first >= 0) tn.medium_first = o.medium_first;
     return tn;
 }
 
@@ -372,6 +373,7 @@ int launch_render(rt_scene *scene, const rt_camera *camera, rt_render_params p, 
     K.lds_world_off = world_in_lds(scene, lds) ? (uint32_t)world_offset(scene, lds) : 0xffffffffu;
     K.box_extent = scene->box_extent;
     K.seq_lookahead = tn.seq_lookahead ? 1u : 0u;
+    K.medium_first = tn.medium_first ? 1u : 0u;
     K.inst_shortcut = tn.start_shortcut ? 1u : 0u;
     K.slow_min = (uint32_t)tn.slow_min; K.slow_age = (uint32_t)tn.slow_age;
     K.o_start_stage = tn.start_shortcut ? scene->o_start_stage : 0u; K.o_start_prim = scene->o_start_prim; K.o_start_end = scene->o_start_end;
@@ -514,6 +516,7 @@ void rt_scene_options_init(rt_scene_options *o) {
     o->reserved_pool = -1;
     o->flat_max = o->start_shortcut = o->defer_instances = o->seq_lookahead = o->slow_min = o->slow_age = o->wide = -1;
     o->quad_filter = -1;
+    o->medium_first = -1;
 }
 
 // (for a caller compiled against an older, shorter struct: nothing beyond ITS size is written)

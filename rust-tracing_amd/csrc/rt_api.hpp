@@ -83,6 +83,7 @@ struct Tuning {
     int jobs_per_grab = 0; // > 0: fixed grab size (RT_JOBS_PER_GRAB; tuning runs)
     int wide = -1;         // own trees with four-child records (rt_layout.h ONode4): 1 always, 0 never, -1 for scenes of 64 primitives or more (RT_WIDE)
     int quad_filter = 1;   // multi-quad leaves go through the conservative f32 filter before the exact test (RT_QUAD_FILTER; rt_scene_options.quad_filter)
+    int medium_first = 1;  // a ray that starts inside a sphere-bounded medium: that medium's draw first, the tree in front of it clipped (RT_MEDIUM_FIRST)
     int overlap = 1;       // 1: a frame of several launches alternates between two scratch sets on two streams (RT_OVERLAP)
     int slow_min = 4, slow_age = 32; // KParams::slow_min / slow_age (RT_SLOW_MIN, RT_SLOW_AGE; slow_min 1: nobody waits)
     int seq_lookahead = 1;  // scenes with media: a query looks ahead at the boxes of the sequence's later steps when it starts (RT_SEQ_LOOKAHEAD)

@@ -85,6 +85,13 @@ struct Rng {
         y = (y << 27) | (y >> 37);
         return xp;
     }
+    // the stream one draw back (next() is a bijection of the state: x' = C y, y' = rotl(y - x, 27); C^-1 mod 2^64 below)
+    RT_DEV void unnext() {
+        const uint64_t y_old = 0x43D68ED20CD1FA63ull * x;
+        const uint64_t diff = (y >> 27) | (y << 37);
+        x = y_old - diff;
+        y = y_old;
+    }
     RT_DEV double random() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
     RT_DEV double range(double lo, double hi) {
         double value1_2 = u2f((next() >> 12) | 0x3ff0000000000000ull);

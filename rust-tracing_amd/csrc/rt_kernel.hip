@@ -173,6 +173,9 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // ---- per-lane traversal state ----
     double cur_tmin = 0.001, cur_tmax = INF; // interval tests run against (ray_color's, or a medium boundary query's)
     double best_t = INF, med_t1 = 0.0;
+    // (ordered walk, media) the draw of the sphere-bounded medium at the NEXT step of the sequence, made before the tree in front of it is
+    // walked — for a ray that starts inside the ball (see where a query starts); NaN: none pending
+    double pre_hd = __builtin_nan("");
     uint32_t best_prim = PRIM_NONE;
     int32_t best_inst = -1, cur_inst = -1;
     uint32_t node = 0, prim_cur = 0, prim_end = 0;
@@ -323,6 +326,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
     // (-inf, inf), then over (t1 + 0.0001, inf)
     auto medium_sphere_hit = [&](uint32_t na, V3 center, V3 center_vec, bool moving, double radius, double neg_inv_density) {
         if (COUNT) { cn.medium_visits++; cn.sphere_tests++; }
+        bool drew = false;
         if (moving) center = center + center_vec * time;
         const V3 oc = o - center;
         const double half_b = dot(oc, d);
@@ -346,8 +350,12 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                         h1 = __builtin_fmax(h1, 0.0);
                         const double ray_length = __builtin_sqrt(len2(d));
                         const double distance_inside_boundary = (h2 - h1) * ray_length;
-                        if (COUNT) cn.rng_draws++;
-                        const double hit_distance = neg_inv_density * rt_log(rng.random());
+                        double hit_distance = pre_hd; // (the draw made where the query started, if one was)
+                        if (!(pre_hd == pre_hd)) {
+                            if (COUNT) cn.rng_draws++;
+                            hit_distance = neg_inv_density * rt_log(rng.random());
+                        }
+                        drew = true;
                         if (hit_distance <= distance_inside_boundary) {
                             best_t = h1 + hit_distance / ray_length;
                             best_prim = PRIM_MEDIUM | na;
@@ -357,6 +365,11 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     }
                 }
             }
+        }
+        if constexpr (ORDERED) {
+            // a draw made ahead that the reference does not make after all (the tree in between hit at exactly t_min): taken back
+            if (pre_hd == pre_hd && !drew) { rng.unnext(); if (COUNT) cn.rng_draws--; }
+            pre_hd = __builtin_nan("");
         }
     };
     // a boundary query (mode 1 or 2) of medium `na` has just ended; true: the second query has to run (interval set)
@@ -400,13 +413,17 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
             // skip the steps whose box the ray cannot reach within (0.001, closest so far): a tree there holds
             // nothing closer, a medium there draws nothing (src/constant_medium.rs:40-44: t1 >= t2)
             stage = ST_SHADE;
+            const bool pending = pre_hd == pre_hd; // (the next step is the medium whose draw was made ahead: never skipped)
+            if (pending) cur_tmax = best_t;        // (the tree in front of it was walked to the draw's candidate only)
+            bool first_step = true;
             while (seq_pc < P.n_oseq) {
                 const OSeq *rec = &seq_tab[seq_pc];
                 seq_pc++;
                 float enter;
                 bool miss0, miss1;
                 box_pair_f32(opair_of_box(rec->box, r32), r32, f32_below(cur_tmin), f32_above(cur_tmax), miss0, miss1, enter, enter);
-                if (miss0) continue;
+                if (miss0 && !(pending && first_step)) continue;
+                first_step = false;
                 if (rec->kind == OSEQ_TREE) {
                     node = rec->a | W_FULL; sp = 0; stage = ST_BOX;
                 } else if (rec->kind == OSEQ_MEDIUM_SPHERE) {
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     auto inside = [&](double root) {
                         if (cur_tmin < root && root < cur_tmax) return true;
                         if constexpr (ORDERED)
-                            return cur_tmin < root && root == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) &&
+                            return cur_tmin < root && root == (HAS_MEDIA ? best_t : cur_tmax) && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) &&
                                    wins_tie(s->seq_moving >> 1, false); // (a boundary query only wants t: ties are moot)
                         return false;
                     };
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     const double t = (qd->d - dot(normal, o)) / denom;
                     if (!(cur_tmin <= t && t <= cur_tmax)) return; // Interval::contains (src/interval.rs:40-42)
                     if constexpr (ORDERED) // the ordered walk settles ties explicitly (see wins_tie)
-                        if (t == cur_tmax && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) && !wins_tie(qd->seq, true)) return;
+                        if (t == (HAS_MEDIA ? best_t : cur_tmax) && best_prim != PRIM_NONE && (!HAS_MEDIA || (mode & 3u) == 0) && !wins_tie(qd->seq, true)) return;
                     if (!inside_known) { // (behind a branch the wave skips when every lane's survivor is a certain one — nearly always)
                         const V3 intersection = o + d * t;
                         const V3 php = intersection - ld3(qd->q);
@@ -1173,6 +1190,39 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     if (first == P.n_oseq) seq_pc = P.n_oseq;
                     else if (seq_tab[first].kind == OSEQ_TREE) seq_pc = first | SEQ_JUMP;
                 }
+                // A ray that STARTS INSIDE the ball of the sphere-bounded medium that follows the tree about to be walked (a scatter inside
+                // final_scene's smoke: a third of its rays) would walk that tree to infinity although the medium nearly always ends the ray
+                // within a few units.  For such a ray the medium's draw happens whatever the tree finds — rec1.t = t_min < rec2.t
+                // (src/constant_medium.rs:40-44) unless the tree hits at exactly t_min, and then the draw is taken back (medium_sphere_hit) —
+                // and its verdict, hit_distance <= (min(exit, closest so far) - t_min) |d|, only turns from yes to no as the tree finds
+                // something closer.  So the draw is made HERE and, where it lands inside the ball, the tree is walked to just beyond the
+                // candidate t (a relative 2^-40: any hit further out leaves the verdict a yes whatever the roundings).  The medium's own step
+                // then evaluates the reference's predicate with the tree's closest hit, which the clipped walk has found if it matters.
+                if (HAS_SPHERES && P.medium_first != 0u && stage == ST_BOX && mode == 0 && seq_pc < P.n_oseq && seq_tab[seq_pc].kind == OSEQ_MEDIUM_SPHERE) {
+                    const OSeq *rec = &seq_tab[seq_pc];
+                    V3 center = ld3(rec->center);
+                    if (rec->moving != 0) center = center + ld3(rec->center_vec) * time;
+                    const V3 oc = o - center;
+                    const double half_b = dot(oc, d);
+                    const double c = len2(oc) - rec->radius * rec->radius;
+                    const double discriminant = half_b * half_b - a * c;
+                    if (!(discriminant < 0.0)) {
+                        const double sqrtd = __builtin_sqrt(discriminant);
+                        const double root_a = (-half_b - sqrtd) / a, root_b = (-half_b + sqrtd) / a;
+                        const double lo2 = root_a + 0.0001;
+                        // (exactly medium_sphere_hit's choices: t1 = root_a <= t_min, t2 = root_b, h1 = t_min)
+                        if (-INF < root_a && root_a <= 0.001 && lo2 < root_b && root_b < INF && 0.001 < __builtin_fmin(root_b, best_t)) {
+                            const double ray_length = __builtin_sqrt(len2(d));
+                            if (COUNT) cn.rng_draws++;
+                            pre_hd = rec->neg_inv_density * rt_log(rng.random());
+                            if (pre_hd <= (__builtin_fmin(root_b, best_t) - 0.001) * ray_length) {
+                                const double t_m = 0.001 + pre_hd / ray_length;
+                                cur_tmax = __builtin_fmin(cur_tmax, t_m + t_m * 0x1p-40);
+                                refresh_interval32();
+                            }
+                        }
+                    }
+                }
             }
         }
     }
@@ -1318,6 +1368,9 @@ __global__ void debug_eval_kernel(int32_t op, int64_t n, const double *__restric
     }
     case RT_DEBUG_RNG_RANGE: {
         Rng g; g.start_key(f2u(x)); for (uint64_t i = 0; i < f2u(y); ++i) g.next(); r = g.range(-1.0, 1.0); break;
+    }
+    case RT_DEBUG_RNG_UNNEXT: { // draw y of the stream, after one draw too many has been taken back
+        Rng g; g.start_key(f2u(x)); for (uint64_t i = 0; i < f2u(y); ++i) g.next(); g.next(); g.next(); g.unnext(); g.unnext(); r = g.random(); break;
     }
     case RT_DEBUG_F32_ABOVE: r = (double)f32_above(x); break;
     case RT_DEBUG_F32_BELOW: r = (double)f32_below(x); break;

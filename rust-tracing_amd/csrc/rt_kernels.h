@@ -82,6 +82,7 @@ struct KParams {
     uint32_t o_start_stage, o_start_prim, o_start_end, o_start_rest, o_start_slot;
     uint32_t inst_shortcut;         // 1: a walk that enters a frame whose tree is one leaf starts with the leaf's primitives (Instance::start_ref)
     uint32_t slow_min, slow_age;    // shade stage: lanes with a dear texture wait for this many of their kind, at most this many shade rounds
+    uint32_t medium_first;          // 1: the draw of a sphere-bounded medium the ray starts inside is made before the tree in front of it is walked (path_kernel)
     uint32_t seq_lookahead;         // 1: a query that cannot reach any later step of the world's sequence ends it at its start (path_kernel)
     uint32_t lds_stack_off;
     uint32_t lds_seq_off;           // the world frame's sequence, copied in by the ordered kernels (after the stacks)

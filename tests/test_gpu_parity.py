@@ -64,6 +64,9 @@ def test_device_arithmetic_matches_oracle(rt, oracle, gpu):
     want_g = np.array([L.orc_kat_gen_range(int(k), int(d), -1.0, 1.0) for k, d in zip(keys, draws)])
     assert_bit_equal(rt.debug_eval(rt.RT_DEBUG_RNG_RANDOM, kf, df), want_r, "random()")
     assert_bit_equal(rt.debug_eval(rt.RT_DEBUG_RNG_RANGE, kf, df), want_g, "gen_range(-1, 1)")
+    # ... and the stream stepped BACK (Rng::unnext: a draw made ahead for a medium that turns out not to draw is taken back): two draws
+    # too many made and undone leave draw n where it was
+    assert_bit_equal(rt.debug_eval(rt.RT_DEBUG_RNG_UNNEXT, kf, df), want_r, "random() after next, next, unnext, unnext")
 
 
 def test_outward_f32_conversions_contain_the_double(rt, gpu):
@@ -346,6 +349,26 @@ def test_shortcuts_and_the_quad_filter_do_the_work_they_claim(rt, gpu):
     # ... and a ray that enters a box's frame but misses the box itself (the frame was met through its wider box in the room's
     # coordinates) does not queue for the faces: a third of the frames entered are not looked at
     assert enters < 0.8 * enters_plain, (enters, enters_plain)
+
+
+def test_the_draw_made_ahead_inside_a_medium_shortens_the_walk(rt, gpu):
+    """final_scene: a third of the rays are scatters inside the smoke ball; the 2407-box tree that precedes the ball in scan order is
+    walked no further than the medium's own candidate — fewer record visits per sample, the same draws, the same frame bit for bit."""
+    import torch
+    hs = scene_cases.build(rt, "c4_final_scene_64x64_8spp_d40")
+    params = rt.render_params(seed=6)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def counted(**opts):
+        ds = rt.DeviceScene(hs, **opts)
+        d = torch.zeros(hs.width * hs.height * 3, dtype=torch.float64, device="cuda")
+        c = ds.render_device_counted(params, d.data_ptr(), stream)
+        return d.cpu().numpy(), c["node_visits"] / c["samples"], c["rng_draws"] / c["samples"]
+
+    img, visits, draws = counted()
+    img_off, visits_off, draws_off = counted(medium_first=0)
+    assert_bit_equal(img, img_off, "medium_first off")
+    assert draws == draws_off and visits < 0.97 * visits_off, (visits, visits_off, draws, draws_off)
 
 
 def test_errors_are_reported_not_thrown(rt, gpu):

@@ -140,23 +140,25 @@ def test_default_choice_of_the_walk(rt, gpu):
         assert rt.DeviceScene(scene_cases.build(rt, name)).stats()["ordered"] == ordered, name
 
 
-@pytest.mark.parametrize("shortcuts", [(0, 0, 0, 0, 1, 0, 1), (8, 0, 1, 1, 64, 3, 0), (0, 1, 0, 1, 2, 1000, 1), (3, 1, 1, 0, 4, 32, 1), (8, 1, 1, 1, 4, 32, 0)])
+@pytest.mark.parametrize("shortcuts", [(0, 0, 0, 0, 1, 0, 1, 0), (8, 0, 1, 1, 64, 3, 0, 1), (0, 1, 0, 1, 2, 1000, 1, 0), (3, 1, 1, 0, 4, 32, 1, 1), (8, 1, 1, 1, 4, 32, 0, 0),
+                                       (8, 1, 1, 0, 4, 32, 1, 0)])
 def test_walk_shortcuts_never_change_the_image(rt, oracle, gpu, shortcuts):
     """Flat leaves for small frames, the start shortcut, instances walked last, the sequence look-ahead, the f32 filter in front of a
-    flat leaf's quads: every combination
-    that differs from the default (8, 1, 1, 1, 4, 32, 1 — which every other test runs; set per scene through rt_scene_options), noise-texture hits waiting in the shade stage included, renders the oracle's image bit for bit."""
+    flat leaf's quads, the draw of a sphere-bounded medium made ahead for a ray that starts inside it: every combination
+    that differs from the default (8, 1, 1, 1, 4, 32, 1, 1 — which every other test runs; set per scene through rt_scene_options), noise-texture hits waiting in the shade stage included, renders the oracle's image bit for bit."""
     lib = rt.amd_lib()
     cam = scene_cases.build(rt, "quads_64x64_8spp")
     scenes = [(name, scene_cases.build(rt, name)) for name in ("c1_random_balls_400x225_10spp_d10", "two_spheres_80x45_8spp", "quads_64x64_8spp",
               "two_perlin_spheres_80x45_8spp", "simple_light_80x45_16spp", "c3_cornell_box_64x64_16spp_d50", "cornell_smoke_64x64_16spp", "c4_final_scene_64x64_8spp_d40")]
-    scenes += [("nested frames", custom_scenes.nested_frames_scene(cam)), ("media 1", custom_scenes.media_scene(cam, 1)),
-               ("ties 2", custom_scenes.tie_scene(cam, 2))]
+    scenes += [("nested frames", custom_scenes.nested_frames_scene(cam)), ("media 0", custom_scenes.media_scene(cam, 0)),
+               ("media 1", custom_scenes.media_scene(cam, 1)), ("media 2", custom_scenes.media_scene(cam, 2)), ("ties 2", custom_scenes.tie_scene(cam, 2))]
     params = rt.render_params(seed=3)
-    flat_max, start_shortcut, defer_instances, seq_lookahead, slow_min, slow_age, quad_filter = shortcuts
+    flat_max, start_shortcut, defer_instances, seq_lookahead, slow_min, slow_age, quad_filter, medium_first = shortcuts
     for name, hs in scenes:
         want = oracle.render(hs, params)
         got = rt.DeviceScene(hs, flat_max=flat_max, start_shortcut=start_shortcut, defer_instances=defer_instances,
-                             seq_lookahead=seq_lookahead, slow_min=slow_min, slow_age=slow_age, quad_filter=quad_filter).render(params)
+                             seq_lookahead=seq_lookahead, slow_min=slow_min, slow_age=slow_age, quad_filter=quad_filter,
+                             medium_first=medium_first).render(params)
         bad = np.flatnonzero(bits(got) != bits(want))
         assert bad.size == 0, f"{name}, shortcuts {shortcuts}: {bad.size} of {want.size} values differ"
 

@@ -20,7 +20,7 @@ for seed in range(first, first + count):
         want = oracle_lib.render(scene, params)
         variants = [dict(walk=rt.RT_WALK_REFERENCE_ORDER), dict(walk=rt.RT_WALK_OWN_TREES, wide=0), dict(walk=rt.RT_WALK_OWN_TREES, wide=1),
                     dict(walk=rt.RT_WALK_OWN_TREES, wide=1, flat_max=seed % 9, leaf_max=1 + seed % 8, start_shortcut=seed % 2, defer_instances=(seed >> 1) % 2,
-                         seq_lookahead=(seed >> 2) % 2, slow_min=1 + seed % 5, slow_age=seed % 40, quad_filter=(seed >> 3) % 2)]
+                         seq_lookahead=(seed >> 2) % 2, slow_min=1 + seed % 5, slow_age=seed % 40, quad_filter=(seed >> 3) % 2, medium_first=(seed >> 4) % 2)]
         for opts in variants:
             got = rt.DeviceScene(scene, **opts).render(params)
             if not np.array_equal(got.view(np.uint64), want.view(np.uint64)):
