@@ -239,9 +239,29 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                     // tree's root at once, not through a round of ST_OTHER that would only have looked the root up
                     if ((seq_pc & SEQ_JUMP) != 0u) {
                         const uint32_t k = seq_pc & ~SEQ_JUMP;
-                        new_node = seq_tab[k].a | W_FULL;
-                        new_stage = ST_BOX;
-                        seq_pc = k + 1u;
+                        bool jump = true;
+                        if (HAS_SPHERES && pre_hd == pre_hd) {
+                            // step k - 1 is the medium whose draw was made ahead.  If the tree in front of it hit nothing within the clipped
+                            // interval, the draw's verdict stands as it was found — the candidate, or nothing — and the walk goes on with the
+                            // tree behind the medium; if it hit something, the medium's own step decides (the reference's predicate with that hit)
+                            const bool tree_hit = best_prim != PRIM_NONE && (best_prim & PRIM_KIND_MASK) != PRIM_MEDIUM;
+                            if (tree_hit) {
+                                jump = false;
+                                seq_pc = k - 1u;
+                                new_node = NODE_SEQ_NEXT;
+                                new_stage = ST_OTHER;
+                            } else {
+                                if (med_t1 == med_t1) { best_t = med_t1; best_prim = PRIM_MEDIUM | seq_tab[k - 1u].a; best_inst = cur_inst; }
+                                cur_tmax = best_t;
+                                tmax32 = f32_above(cur_tmax);
+                                pre_hd = __builtin_nan("");
+                            }
+                        }
+                        if (jump) {
+                            new_node = seq_tab[k].a | W_FULL;
+                            new_stage = ST_BOX;
+                            seq_pc = k + 1u;
+                        }
                     }
                 }
             }
@@ -1215,11 +1235,16 @@ __global__ __launch_bounds__(THREADS, LDS ? 1 : RT_MIN_WAVES) void path_kernel(c
                             const double ray_length = __builtin_sqrt(len2(d));
                             if (COUNT) cn.rng_draws++;
                             pre_hd = rec->neg_inv_density * rt_log(rng.random());
+                            med_t1 = __builtin_nan(""); // (free outside boundary queries: the candidate t, if the draw lands inside the ball)
                             if (pre_hd <= (__builtin_fmin(root_b, best_t) - 0.001) * ray_length) {
                                 const double t_m = 0.001 + pre_hd / ray_length;
+                                med_t1 = t_m;
                                 cur_tmax = __builtin_fmin(cur_tmax, t_m + t_m * 0x1p-40);
                                 refresh_interval32();
                             }
+                            // where a TREE follows the medium, the medium's step is settled where the walk of the tree in front of it ends
+                            // (o_next), without a round of ST_OTHER, unless that walk hit something
+                            if (seq_pc + 1u < P.n_oseq && seq_tab[seq_pc + 1u].kind == OSEQ_TREE) seq_pc = (seq_pc + 1u) | SEQ_JUMP;
                         }
                     }
                 }
